@@ -1,0 +1,90 @@
+"""ctypes binding of the C-ABI library (include/als_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` /
+`make -C collaborative-filtering_amd/csrc`.  There is no CPU fallback: if the
+library is missing or a symbol is absent, import of the binding raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libals_hip.so")
+
+SPLIT_CHUNK = 4096          # ALS_SPLIT_CHUNK
+MAX_K = 160                 # ALS_MAX_K
+
+EXPORTS = ("als_version", "als_padded_k", "als_perm_index", "als_partial_slot_bytes",
+           "als_row_solve", "als_gs_sweep", "als_residual_stats", "als_sumsq_partials",
+           "als_sumsq", "als_compose_z", "als_predict_at", "als_predict_dense")
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class RowSolveParams(C.Structure):
+    """struct als_row_solve_params (include/als_hip.h)."""
+    _fields_ = [
+        ("k", _i32), ("ld", _i32), ("nrows", _i64),
+        ("indptr", _vp), ("indices", _vp), ("vals", _vp), ("F", _vp),
+        ("bias_self", _vp), ("bias_other", _vp), ("mu", _vp),
+        ("lambda_scalar", _f32), ("lambda_row", _vp),
+        ("lambda_bias_scalar", _f32), ("lambda_bias_row", _vp),
+        ("rhs_extra", _vp), ("diag_extra", _vp),
+        ("X_out", _vp), ("bias_out", _vp), ("gram_out", _vp), ("factor_out", _vp),
+        ("rhs_out", _vp), ("colsum_out", _vp), ("sumr_out", _vp), ("status", _vp),
+        ("tasks", _vp), ("ntasks", _i64), ("long_rows", _vp), ("nlong", _i64),
+        ("workspace", _vp),
+    ]
+
+
+class GsSweepParams(C.Structure):
+    """struct als_gs_sweep_params (include/als_hip.h)."""
+    _fields_ = [
+        ("k", _i32), ("ld", _i32), ("items", _vp), ("nitems", _i64),
+        ("S_ptr", _vp), ("S_idx", _vp), ("S_val", _vp), ("alpha", _f32),
+        ("factor", _vp), ("rhs", _vp), ("colsum", _vp), ("sumr", _vp),
+        ("indptr", _vp), ("lambda_bias_scalar", _f32), ("lambda_bias_row", _vp),
+        ("V", _vp), ("bias", _vp),
+    ]
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libals_hip.so and declare prototypes (idempotent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C collaborative-filtering_amd/csrc`. There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise HipLibraryMissing(f"{LIB_PATH} does not export {name}")
+    lib.als_version.restype = C.c_int
+    lib.als_padded_k.argtypes = [C.c_int]
+    lib.als_perm_index.argtypes = [C.c_int, C.c_int]
+    lib.als_partial_slot_bytes.argtypes = [C.c_int]
+    lib.als_partial_slot_bytes.restype = _i64
+    lib.als_row_solve.argtypes = [C.POINTER(RowSolveParams), _vp]
+    lib.als_gs_sweep.argtypes = [C.POINTER(GsSweepParams), _vp]
+    lib.als_residual_stats.argtypes = [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                       _vp, _i64, _vp, _vp, _vp]
+    lib.als_sumsq_partials.restype = C.c_int
+    lib.als_sumsq.argtypes = [_vp, _i64, _vp, _vp, _vp]
+    lib.als_compose_z.argtypes = [_i64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
+    lib.als_predict_at.argtypes = [C.c_int, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.als_predict_dense.argtypes = [C.c_int, C.c_int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+    for name in EXPORTS:
+        if name != "als_partial_slot_bytes":
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib

@@ -1,0 +1,571 @@
+"""`ALS` - the reference's fit / predict surface on MI355X.
+
+Mirror of `scripts/als.py` (class ALS, :104-574) of
+zhukovanadezhda/collaborative-filtering: same constructor, `fit`, `predict`,
+attributes (`U V W b_u b_i mu S history`) and error behaviour, so it stands in
+behind `scripts/evaluate_models.py:246-254` and `scripts/tune_params.py:376-391`.
+The arithmetic is not numpy: ratings live as CSR + CSC in HBM and every
+per-row / per-rating step runs in the HIP kernels behind include/als_hip.h.
+
+Build-only additions (keyword arguments with defaults, so the reference
+signature is unchanged):
+  ALS(..., device=, backend=, gs_mode=, process_group=)
+  fit(..., S=)              precomputed similarity graph as CSR (ptr, idx, val)
+  fit_coo(rows, cols, vals, shape, ...)   sparse-native entry for large inputs
+  predict_at(flat_idx, ...) predictions at flat indices u*n+i without the
+                            dense m x n matrix
+"""
+from __future__ import annotations
+
+import logging
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import layout
+from .als_config import ALSConfig
+
+SCALE_FACTOR = 0.1      # scripts/als.py:93
+EPS = 1e-10             # scripts/als.py:94
+
+logger = logging.getLogger(__name__)
+
+
+@dataclass
+class _SideDev:
+    nrows: int
+    ncols: int
+    indptr: torch.Tensor
+    indices: torch.Tensor
+    vals: torch.Tensor
+
+
+@dataclass
+class _TasksDev:
+    tasks: torch.Tensor
+    long_rows: torch.Tensor
+    ntasks: int
+    nlong: int
+    nslots: int
+    nnz: int
+
+
+def _side_to_dev(s: layout.SparseSide, device) -> _SideDev:
+    return _SideDev(s.nrows, s.ncols,
+                    torch.from_numpy(s.indptr).to(device),
+                    torch.from_numpy(s.indices).to(device),
+                    torch.from_numpy(s.vals).to(device))
+
+
+def _tasks_to_dev(t: layout.RowTasks, device) -> _TasksDev:
+    return _TasksDev(torch.from_numpy(t.tasks).to(device), torch.from_numpy(t.long_rows).to(device),
+                     int(t.tasks.shape[0]), int(t.long_rows.shape[0]), t.nslots, t.nnz)
+
+
+class ALS:
+    """Alternating least squares with biases, feature projections and a graph
+    Laplacian:  R ~ U (V + sum_f X_f W_f)^T + mu + b_u + b_i."""
+
+    def __init__(self, config: ALSConfig, lambda_w: Optional[Dict[str, float]] = None, *,
+                 device=None, backend=None, gs_mode: Optional[str] = None, process_group=None) -> None:
+        if config is None:                                   # scripts/als.py:146-147
+            raise ValueError("ALSConfig must be provided.")
+        self.cfg = config
+        self.W: Dict[str, np.ndarray] = {}
+        self.lambda_w: Dict[str, float] = dict(lambda_w or {})
+        core = config.core
+        self.n_factors = core.n_factors
+        self.n_iters = core.n_iters
+        self.lambda_u = core.lambda_u
+        self.lambda_v = core.lambda_v
+        self.random_state = core.random_state
+        self.update_w_every = core.update_w_every
+        self.pop_reg_mode = core.pop_reg_mode
+        # reference `or` rule: None and 0.0 both fall back (scripts/als.py:166-167)
+        self.lambda_bu = config.biases.lambda_bu or self.lambda_u
+        self.lambda_bi = config.biases.lambda_bi or self.lambda_v
+        self.alpha = config.graph.alpha
+        sim = config.graph.sim
+        self.S_topk = sim.topk if sim is not None else None
+        self.S_eps = sim.eps if sim is not None else EPS
+        self.U = self.V = self.b_u = self.b_i = None
+        self.mu: float = 0.0
+        self.S = None
+        self.history: Dict[str, list] = {"train_rmse": [], "U_norm": [], "V_norm": [],
+                                         "bu_norm": [], "bi_norm": []}
+        # build-only state
+        self._device = torch.device(device) if device is not None else None
+        self._backend = backend
+        self._gs_mode = gs_mode
+        self._pg = process_group
+        self._eng: Optional[_Engine] = None
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, R: np.ndarray, features: Optional[Dict[str, np.ndarray]] = None,
+            tol: Optional[float] = 1e-3, min_iters: int = 5, verbose: int = 1, *, S=None) -> "ALS":
+        """Fit on a dense (m, n) matrix with NaN for missing (scripts/als.py:300-529)."""
+        R = np.asarray(R)
+        ru, ri, rv = layout.dense_to_coo(R)
+        return self.fit_coo(ru, ri, rv, R.shape, features=features, tol=tol, min_iters=min_iters,
+                            verbose=verbose, S=S)
+
+    def fit_coo(self, rows, cols, vals, shape, features: Optional[Dict[str, np.ndarray]] = None,
+                tol: Optional[float] = 1e-3, min_iters: int = 5, verbose: int = 1, *, S=None) -> "ALS":
+        """Same as `fit` on COO triplets; nothing dense m x n is ever formed."""
+        m, n = int(shape[0]), int(shape[1])
+        features = features or {}
+        for name, X in features.items():                     # scripts/als.py:346-351
+            if X.shape[0] != n:
+                raise ValueError(f"Feature '{name}' has {X.shape[0]} rows; "
+                                 f"expected {n} (number of items).")
+            if not np.isfinite(X).all():
+                raise ValueError(f"Feature '{name}' contains infinite values.")
+        if self.pop_reg_mode and self.pop_reg_mode != "inverse_sqrt":   # scripts/als.py:259
+            raise ValueError(f"Unknown pop_reg_mode '{self.pop_reg_mode}'")
+
+        # graph (scripts/als.py:354-357): on iff alpha > 0, sim configured, graph available
+        S_csr = None
+        self.S = None
+        if (self.alpha > 0.0) and (self.cfg.graph.sim is not None):
+            if S is not None:
+                S_csr = (np.asarray(S[0], np.int64), np.asarray(S[1], np.int32), np.asarray(S[2], np.float32))
+                self.S = S_csr
+            else:
+                X = features.get(self.cfg.graph.sim.feature_name)
+                if X is None:                                # scripts/als.py:219-222
+                    logger.warning("GraphSim feature '%s' not found in features dict. "
+                                   "Graph regularization disabled.", self.cfg.graph.sim.feature_name)
+                else:
+                    Sd = layout.build_similarity_dense(X, self.S_topk, self.S_eps)
+                    self.S = Sd
+                    ptr, idx, val = layout.dense_graph_to_csr(Sd)
+                    # D = S.sum(axis=1) exactly as the reference forms it (:357)
+                    S_csr = (ptr, idx, val.astype(np.float32), Sd.sum(axis=1).astype(np.float32))
+
+        device = self._device or torch.device("cuda", torch.cuda.current_device()
+                                              if torch.cuda.is_available() else 0)
+        backend = self._backend
+        if backend is None:
+            from .backend import HipBackend
+            backend = HipBackend(device)
+        csr, csc = layout.coo_to_sides(rows, cols, vals, (m, n))
+        self._eng = _Engine(self, csr, csc, features, S_csr, device, backend, self._pg, self._gs_mode)
+        if verbose > 0:
+            logger.info("Starting ALS training: n_factors=%d, n_iters=%d, lambda_u=%s, lambda_v=%s, "
+                        "pop_reg_mode=%s, features=%s, lambda_w=%s, random_state=%s, graph_alpha=%s, "
+                        "update_w_every=%s, world=%d", self.n_factors, self.n_iters, self.lambda_u,
+                        self.lambda_v, self.pop_reg_mode, list(features), self.lambda_w,
+                        self.random_state, self.alpha, self.update_w_every, self._eng.world)
+        self._eng.run(tol, min_iters, verbose)
+        self._eng.export(self)
+        if verbose > 0 and self.history["train_rmse"]:
+            logger.info("ALS training finished. Final train RMSE: %.4f", self.history["train_rmse"][-1])
+        return self
+
+    # -------------------------------------------------------------- predict
+    def _check_predict(self, features):
+        if self.U is None or self.V is None:                 # scripts/als.py:554-555
+            raise RuntimeError("Model must be fitted before prediction.")
+        n = self.V.shape[0]
+        features = features or {}
+        for name, X in features.items():                     # scripts/als.py:560-565
+            if X.shape[0] != n:
+                raise ValueError(f"Feature '{name}' has {X.shape[0]} rows. "
+                                 f"Expected number of rows: {n}.")
+            if not np.isfinite(X).all():
+                raise ValueError(f"Feature '{name}' contains infinite values.")
+        return features
+
+    def predict(self, features: Optional[Dict[str, np.ndarray]] = None) -> np.ndarray:
+        """Completed matrix U Z^T + mu + b_u + b_i, (m, n) float64 (scripts/als.py:532-574)."""
+        features = self._check_predict(features)
+        return self._eng.predict_dense(features)
+
+    def predict_at(self, flat_idx, features: Optional[Dict[str, np.ndarray]] = None) -> np.ndarray:
+        """Predictions at flat indices u*n+i (what scripts/tune_params.py:165-166 reads)."""
+        features = self._check_predict(features)
+        return self._eng.predict_at(np.asarray(flat_idx, dtype=np.int64), features)
+
+
+class _Engine:
+    """Device state and the iteration loop of one `fit`."""
+
+    def __init__(self, model: ALS, csr, csc, features, S_csr, device, backend, pg, gs_mode):
+        self.model = model
+        self.dev = device
+        self.be = backend
+        self.pg = pg
+        if pg is not None or (dist.is_available() and dist.is_initialized()):
+            self.world, self.rank = dist.get_world_size(pg), dist.get_rank(pg)
+        else:
+            self.world, self.rank = 1, 0
+        k = int(model.n_factors)
+        self.k, self.ld = k, layout.padded_k(k)
+        self.m, self.n = csr.nrows, csc.nrows
+        self.nnz = int(csr.vals.shape[0])
+        self.perm = torch.from_numpy(layout.perm_of_col(k)).to(device)     # storage col -> perm pos
+        f32, f64 = torch.float32, torch.float64
+
+        # --- shards (contiguous, equal row counts; storage padded to world * per)
+        self.u_per, ub = layout.shard_bounds(self.m, self.world)
+        self.i_per, ib = layout.shard_bounds(self.n, self.world)
+        self.ub, self.ue = ub[self.rank]
+        self.ib, self.ie = ib[self.rank]
+        m_pad, n_pad = self.u_per * self.world, self.i_per * self.world
+        self.m_pad, self.n_pad = m_pad, n_pad
+
+        # --- ratings in HBM
+        self.csr = _side_to_dev(csr, device)
+        self.csc = _side_to_dev(csc, device)
+        self.utasks = _tasks_to_dev(layout.build_row_tasks(csr.indptr, self.ub, self.ue), device)
+        self.itasks = _tasks_to_dev(layout.build_row_tasks(csc.indptr, self.ib, self.ie), device)
+        nslots = max(self.utasks.nslots, self.itasks.nslots)
+        self.workspace = (torch.empty(nslots * backend.slot_bytes(k) // 4, dtype=f32, device=device)
+                          if nslots else None)
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)
+
+        # --- parameters (scripts/als.py:329,360-376): numpy Generator on the host, same draw order
+        rng = np.random.default_rng(model.random_state)
+        self.mu = torch.tensor([float(np.mean(csr.vals.astype(np.float64))) if self.nnz else float("nan")],
+                               dtype=f64, device=device)
+        U0 = rng.normal(scale=SCALE_FACTOR, size=(self.m, k))
+        V0 = rng.normal(scale=SCALE_FACTOR, size=(self.n, k))
+        self.U = self._padded(U0, m_pad)
+        self.V = self._padded(V0, n_pad)
+        self.b_u = torch.zeros(m_pad, dtype=f32, device=device)
+        self.b_i = torch.zeros(n_pad, dtype=f32, device=device)
+        self.feat_names = list(features)
+        self.feat_dims = [int(features[f].shape[1]) for f in self.feat_names]
+        self.W64 = {}
+        for f in self.feat_names:
+            self.W64[f] = torch.from_numpy(rng.normal(scale=SCALE_FACTOR, size=(features[f].shape[1], k))).to(device)
+        if self.feat_names:
+            Xcat = np.concatenate([np.asarray(features[f], dtype=np.float32) for f in self.feat_names], axis=1)
+            Xp = np.zeros((n_pad, Xcat.shape[1]), dtype=np.float32)
+            Xp[: self.n] = Xcat
+            self.Xcat = torch.from_numpy(Xp).to(device)
+            self.X64 = {f: torch.from_numpy(np.asarray(features[f], dtype=np.float64)).to(device)
+                        for f in self.feat_names}
+            self.Wcat = torch.zeros(Xcat.shape[1], self.ld, dtype=f32, device=device)
+            self.Z = torch.zeros(n_pad, self.ld, dtype=f32, device=device)
+            self._sync_wcat()
+        else:
+            self.Xcat = self.Wcat = None
+            self.Z = self.V                       # Z == V when there are no features
+
+        # --- per-item regularisation (scripts/als.py:379-384, 243-259)
+        counts = np.diff(csc.indptr).astype(np.float64)
+        if not model.pop_reg_mode:
+            lam_v = np.full(self.n, float(model.lambda_v))
+        else:
+            lam_v = model.lambda_v / np.sqrt(counts + 1.0)
+        lv = np.zeros(n_pad, dtype=np.float32)
+        lv[: self.n] = lam_v
+        self.lam_v_row = torch.from_numpy(lv).to(device)
+
+        # --- graph
+        self.use_graph = S_csr is not None
+        if self.use_graph:
+            ptr, idx, val = S_csr[0], S_csr[1], S_csr[2]
+            if len(S_csr) > 3:
+                D = S_csr[3]
+            else:
+                D = np.zeros(self.n, dtype=np.float32)
+                np.add.at(D, np.repeat(np.arange(self.n), np.diff(ptr)), val)
+            self.S_ptr = torch.from_numpy(np.ascontiguousarray(ptr)).to(device)
+            self.S_idx = torch.from_numpy(np.ascontiguousarray(idx)).to(device)
+            self.S_val = torch.from_numpy(np.ascontiguousarray(val)).to(device)
+            de = np.zeros(n_pad, dtype=np.float32)
+            de[: self.n] = np.float32(model.alpha) * D.astype(np.float32)
+            self.diag_extra = torch.from_numpy(de).to(device)
+            self.gs_mode = gs_mode or ("exact" if self.world == 1 else "block")
+            if self.gs_mode not in ("exact", "block"):
+                raise ValueError(f"unknown gs_mode '{self.gs_mode}'")
+            active = counts > 0
+            if self.gs_mode == "block" or self.world == 1:
+                sched = layout.build_level_schedule(ptr, idx, active, self.ib, self.ie)
+            else:
+                sched = layout.build_level_schedule(ptr, idx, active, 0, self.n)
+            self.sched = sched
+            self.sched_items = torch.from_numpy(sched.items).to(device)
+            self.factor = torch.zeros(n_pad * self.ld * self.ld, dtype=f32, device=device)
+            self.sumr = torch.zeros(n_pad, dtype=f32, device=device)
+        need_byproducts = self.use_graph or bool(self.feat_names)
+        self.rhs_out = torch.zeros(n_pad, self.ld, dtype=f32, device=device) if need_byproducts else None
+        self.colsum_out = torch.zeros(n_pad, self.ld, dtype=f32, device=device) if need_byproducts else None
+        self.gram = (torch.zeros(n_pad, self.ld, self.ld, dtype=f32, device=device)
+                     if self.feat_names else None)
+
+        # --- stats scratch
+        self.stats = torch.zeros(2, dtype=f64, device=device)
+        self.ss = torch.zeros(4, dtype=f64, device=device)
+        self.hist = torch.zeros(max(model.n_iters, 1), 6, dtype=f64, device=device)
+        self.iters_run = 0
+
+    # ------------------------------------------------------------- helpers
+    def _padded(self, A64: np.ndarray, rows_pad: int) -> torch.Tensor:
+        out = np.zeros((rows_pad, self.ld), dtype=np.float32)
+        out[: A64.shape[0], : self.k] = A64
+        return torch.from_numpy(out).to(self.dev)
+
+    def _sync_wcat(self):
+        off = 0
+        for f, d in zip(self.feat_names, self.feat_dims):
+            self.Wcat[off:off + d, : self.k] = self.W64[f].to(torch.float32)
+            off += d
+
+    def _allgather_rows(self, t: torch.Tensor, per: int):
+        """In-place all-gather of equal contiguous row shards of `t`."""
+        if self.world == 1:
+            return
+        mine = t[self.rank * per:(self.rank + 1) * per].clone()
+        dist.all_gather_into_tensor(t.view(-1), mine.view(-1), group=self.pg)
+
+    def _allreduce(self, t: torch.Tensor):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def _check_status(self):
+        bad = int(self.status.item())
+        if bad:
+            self.status.zero_()
+            raise np.linalg.LinAlgError(
+                f"normal equations of row {bad - 1} are not positive definite")   # scripts/helpers.py:19
+
+    # ---------------------------------------------------------- half steps
+    def user_step(self):
+        """scripts/als.py:414-433 on this rank's user shard, then all-gather."""
+        md = self.model
+        self.be.row_solve(k=self.k, ld=self.ld, side=self.csr, F=self.Z, bias_self=self.b_u,
+                          bias_other=self.b_i, mu=self.mu, lam=md.lambda_u, lam_row=None,
+                          lam_b=md.lambda_bu, lam_b_row=None, rhs_extra=None, diag_extra=None,
+                          X_out=self.U, bias_out=self.b_u, gram_out=None, factor_out=None,
+                          rhs_out=None, colsum_out=None, sumr_out=None, status=self.status,
+                          tasks=self.utasks, workspace=self.workspace)
+        self._allgather_rows(self.U, self.u_per)
+        self._allgather_rows(self.b_u, self.u_per)
+
+    def item_step(self, want_gram: bool):
+        """scripts/als.py:436-466 on this rank's item shard, then all-gather.
+
+        The feature part of Z is deliberately not used here (reference quirk,
+        :447,:465): F = U, and the bias update uses V, not Z.
+        """
+        md = self.model
+        common = dict(k=self.k, ld=self.ld, side=self.csc, F=self.U, bias_self=self.b_i,
+                      bias_other=self.b_u, mu=self.mu, lam=0.0, lam_row=self.lam_v_row,
+                      lam_b=md.lambda_bi, lam_b_row=None, rhs_extra=None,
+                      gram_out=self.gram if want_gram else None, status=self.status,
+                      tasks=self.itasks, workspace=self.workspace)
+        if not self.use_graph:
+            self.be.row_solve(diag_extra=None, X_out=self.V, bias_out=self.b_i, factor_out=None,
+                              rhs_out=self.rhs_out if want_gram else None,
+                              colsum_out=self.colsum_out if want_gram else None, sumr_out=None, **common)
+        else:
+            # phase A (parallel): Gram, rhs, Cholesky factor of every item of the shard
+            self.be.row_solve(diag_extra=self.diag_extra, X_out=None, bias_out=None, factor_out=self.factor,
+                              rhs_out=self.rhs_out, colsum_out=self.colsum_out, sumr_out=self.sumr, **common)
+            # phase B (sequential in levels): Gauss-Seidel sweep with live V (:458)
+            self._gs_sweep()
+        self._allgather_rows(self.V, self.i_per)
+        self._allgather_rows(self.b_i, self.i_per)
+
+    def _gs_sweep(self):
+        md = self.model
+        off = self.sched.offsets
+        exact_multi = self.world > 1 and self.gs_mode == "exact"
+        for lv in range(len(off) - 1):
+            items = self.sched_items[off[lv]:off[lv + 1]]
+            if exact_multi:
+                it_np = self.sched.items[off[lv]:off[lv + 1]]
+                lo = int(np.searchsorted(it_np, self.ib))
+                hi = int(np.searchsorted(it_np, self.ie))
+                mine = items[lo:hi]
+            else:
+                mine = items
+            if mine.numel():
+                self.be.gs_level(k=self.k, ld=self.ld, items=mine, S_ptr=self.S_ptr, S_idx=self.S_idx,
+                                 S_val=self.S_val, alpha=md.alpha, factor=self.factor, rhs=self.rhs_out,
+                                 colsum=self.colsum_out, sumr=self.sumr, indptr=self.csc.indptr,
+                                 lam_b=md.lambda_bi, lam_b_row=None, V=self.V, bias=self.b_i)
+            if exact_multi:
+                self._exchange_level(items, it_np)
+
+    def _exchange_level(self, items: torch.Tensor, it_np: np.ndarray):
+        """Exact multi-GPU sweep: publish this level's freshly solved V rows."""
+        owner = np.minimum(it_np // self.i_per, self.world - 1)
+        cnt = np.bincount(owner, minlength=self.world)
+        cmax = int(cnt.max())
+        if cmax == 0:
+            return
+        lo = int(np.searchsorted(it_np, self.ib))
+        buf = torch.zeros(cmax, self.ld, dtype=torch.float32, device=self.dev)
+        n_mine = int(cnt[self.rank])
+        if n_mine:
+            buf[:n_mine] = self.V[items[lo:lo + n_mine].long()]
+        allb = torch.empty(self.world * cmax, self.ld, dtype=torch.float32, device=self.dev)
+        dist.all_gather_into_tensor(allb.view(-1), buf.view(-1), group=self.pg)
+        start = 0
+        for r in range(self.world):
+            c = int(cnt[r])
+            if c and r != self.rank:
+                self.V[items[start:start + c].long()] = allb[r * cmax:r * cmax + c]
+            start += c
+
+    # --------------------------------------------------------------- W step
+    def w_step(self, b_i_old: torch.Tensor):
+        """scripts/als.py:468-501 without the N_obs x (d k) design matrix.
+
+        With G_i = U_i^T U_i (the item Gram of this iteration's V-step) the
+        reference's normal equations are
+            A_f = sum_i (x_i x_i^T) (x) G_i + (lambda_f + 1e-10) I
+            b_f = sum_i x_i (x) (g_i + G_i xw_{f,i}),   g_i = U_i^T residual_i
+        and g_i = U_i^T rho_i - G_i z_i follows from the V-step by-products
+        (rhs, column sums), so no extra pass over the ratings is needed.  The
+        Jacobi-across-features quirk (:474-489) and the lambda=0-for-missing
+        quirk (:497) are kept.  Dense algebra in fp64 (library GEMM + potrf).
+        """
+        md = self.model
+        k, ld = self.k, self.ld
+        f64 = torch.float64
+        sl = slice(self.ib, self.ie)
+        # perm-space -> storage order, real columns only
+        pos = self.perm[:ld]                       # pos[c] = perm position of storage col c
+        pk = pos[:k]
+        Graw = self.gram[sl]                       # [nl, ld, ld] perm space, upper blocks valid
+        blk = torch.arange(ld, device=self.dev) // 16
+        up = (blk[:, None] <= blk[None, :])
+        sup = (blk[:, None] < blk[None, :])
+        Gup = torch.where(up, Graw, torch.zeros((), dtype=Graw.dtype, device=self.dev))
+        Gfull = Gup + torch.where(sup, Graw, torch.zeros((), dtype=Graw.dtype, device=self.dev)).transpose(1, 2)
+        G = Gfull[:, pk][:, :, pk].to(f64)         # [nl, k, k] storage order
+        rhs = self.rhs_out[sl][:, pk].to(f64)      # U_i^T r_i with the old b_i
+        cs = self.colsum_out[sl][:, pk].to(f64)
+        db = (self.b_i[sl].to(f64) - b_i_old[sl].to(f64))[:, None]
+        Ut_rho = rhs - db * cs
+        V64 = self.V[sl, :k].to(f64)
+        xw = {f: self.X64[f][sl] @ self.W64[f] for f in self.feat_names}     # old W
+        z = V64.clone()
+        for f in self.feat_names:
+            z += xw[f]
+        g = Ut_rho - torch.bmm(G, z.unsqueeze(2)).squeeze(2)
+        newW = {}
+        Gflat = G.reshape(G.shape[0], k * k)
+        for f, d in zip(self.feat_names, self.feat_dims):
+            X = self.X64[f][sl]
+            h = g + torch.bmm(G, xw[f].unsqueeze(2)).squeeze(2)
+            B = X.transpose(0, 1) @ h                                      # [d, k]
+            Pm = (X[:, :, None] * X[:, None, :]).reshape(X.shape[0], d * d)
+            T = Pm.transpose(0, 1) @ Gflat                                  # [d*d, k*k]
+            A = T.reshape(d, d, k, k).permute(0, 2, 1, 3).reshape(d * k, d * k).contiguous()
+            if self.world > 1:
+                self._allreduce(A)
+                self._allreduce(B)
+            lam = float(md.lambda_w.get(f, 0.0))
+            A.diagonal().add_(lam + EPS)
+            L, info = torch.linalg.cholesky_ex(A)
+            if int(info.item()) != 0:
+                raise np.linalg.LinAlgError(f"W-step normal equations of feature '{f}' are not positive definite")
+            newW[f] = torch.cholesky_solve(B.reshape(d * k, 1), L).reshape(d, k)
+        self.W64.update(newW)
+        self._sync_wcat()
+
+    # ---------------------------------------------------------------- stats
+    def stats_step(self, it: int):
+        """scripts/als.py:503-517: mu update and the five history series."""
+        if self.feat_names:
+            self.be.compose_z(self.V, self.Xcat, self.Wcat, self.Z)              # :504
+        self.be.residual_stats(k=self.k, ld=self.ld, side=self.csr, U=self.U, Z=self.Z, b_u=self.b_u,
+                               b_i=self.b_i, mu=self.mu, tasks=self.utasks, out=self.stats)
+        self._allreduce(self.stats)
+        for j, t in enumerate((self.U, self.V, self.b_u, self.b_i)):
+            self.be.sumsq(t, self.ss[j:j + 1])
+        mean_d = self.stats[0] / self.nnz
+        self.mu += mean_d
+        h = self.hist[it]
+        h[0] = torch.sqrt(torch.clamp(self.stats[1] / self.nnz - mean_d * mean_d, min=0.0))
+        h[1:5] = torch.sqrt(self.ss)
+        h[5] = self.mu[0]
+
+    # ------------------------------------------------------------------ run
+    def run(self, tol, min_iters, verbose):
+        md = self.model
+        n_iters = int(md.n_iters)
+        has_feat = bool(self.feat_names)
+        rm = md.history["train_rmse"]
+        base_len = len(rm)
+        if has_feat:
+            self.be.compose_z(self.V, self.Xcat, self.Wcat, self.Z)              # :411
+        for it in range(n_iters):
+            # Z is current here: stats_step recomposes it after every V / W update
+            self.user_step()
+            do_w = has_feat and ((it % md.update_w_every == 0) or (it == n_iters - 1))   # :468
+            b_i_old = self.b_i.clone() if do_w else None
+            self.item_step(want_gram=do_w)
+            if do_w:
+                self.w_step(b_i_old)
+            self.stats_step(it)
+            self.iters_run = it + 1
+            if tol is not None and it + 1 >= min_iters:                           # :520-523
+                self._check_status()
+                h = self.hist[: it + 1, 0].cpu().numpy()
+                if len(h) + base_len >= 3:
+                    prev = (list(rm) + list(h))[-3]
+                    if prev - h[-1] <= tol:
+                        if verbose > 0:
+                            logger.info("Early stopping at iter %d; dRMSE <= %.3g", it + 1, tol)
+                        break
+        self._check_status()
+
+    # --------------------------------------------------------------- export
+    def export(self, model: ALS):
+        k = self.k
+        model.U = self.U[: self.m, :k].to(torch.float64).cpu().numpy()
+        model.V = self.V[: self.n, :k].to(torch.float64).cpu().numpy()
+        model.b_u = self.b_u[: self.m].to(torch.float64).cpu().numpy()
+        model.b_i = self.b_i[: self.n].to(torch.float64).cpu().numpy()
+        model.mu = float(self.mu.item())
+        for f in self.feat_names:
+            model.W[f] = self.W64[f].cpu().numpy()
+        h = self.hist[: self.iters_run].cpu().numpy()
+        for j, key in enumerate(("train_rmse", "U_norm", "V_norm", "bu_norm", "bi_norm")):
+            model.history[key].extend(float(x) for x in h[:, j])
+
+    # -------------------------------------------------------------- predict
+    def _compose_for(self, features):
+        """Z for `features` as passed to predict (scripts/als.py:568-572)."""
+        names = [f for f in features if f in self.W64]
+        if not names:
+            return self.V
+        Xcat = np.concatenate([np.asarray(features[f], dtype=np.float32) for f in names], axis=1)
+        Xp = np.zeros((self.n_pad, Xcat.shape[1]), dtype=np.float32)
+        Xp[: self.n] = Xcat
+        W = torch.zeros(Xcat.shape[1], self.ld, dtype=torch.float32, device=self.dev)
+        off = 0
+        for f in names:
+            d = features[f].shape[1]
+            W[off:off + d, : self.k] = self.W64[f].to(torch.float32)
+            off += d
+        Z = torch.empty_like(self.V)
+        self.be.compose_z(self.V, torch.from_numpy(Xp).to(self.dev), W, Z)
+        return Z
+
+    def predict_dense(self, features) -> np.ndarray:
+        Z = self._compose_for(features)
+        out = torch.empty(self.m, self.n, dtype=torch.float32, device=self.dev)
+        self.be.predict_dense(k=self.k, ld=self.ld, m=self.m, n=self.n, U=self.U, Z=Z, b_u=self.b_u,
+                              b_i=self.b_i, mu=self.mu, out=out)
+        return out.cpu().numpy().astype(np.float64)
+
+    def predict_at(self, flat_idx: np.ndarray, features) -> np.ndarray:
+        Z = self._compose_for(features)
+        u, i = np.divmod(flat_idx, self.n)
+        us = torch.from_numpy(u.astype(np.int32)).to(self.dev)
+        is_ = torch.from_numpy(i.astype(np.int32)).to(self.dev)
+        out = torch.empty(flat_idx.shape[0], dtype=torch.float32, device=self.dev)
+        self.be.predict_at(k=self.k, ld=self.ld, us=us, is_=is_, U=self.U, Z=Z, b_u=self.b_u,
+                           b_i=self.b_i, mu=self.mu, out=out)
+        return out.cpu().numpy().astype(np.float64)

@@ -1,0 +1,107 @@
+"""HIP backend: torch tensors in, C-ABI calls out (include/als_hip.h).
+
+torch is used for what it is good at here - device memory, streams, and the
+process group.  All arithmetic of the per-rating / per-row hot path happens in
+the hand-written kernels behind the C ABI.  The engine (als.py) talks to this
+object only through the methods below, so that the sharding / collective logic
+can be exercised on CPU under gloo with a stand-in solver living in tests/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _hip
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError("HipBackend needs a ROCm device (torch device type 'cuda'); "
+                               "there is no CPU path in the product")
+        self.lib = _hip.load()
+        self.device = device
+        self._sumsq_partials = torch.empty(self.lib.als_sumsq_partials(), dtype=torch.float64,
+                                           device=device)
+        self._stats_partials: Optional[torch.Tensor] = None
+
+    # -- helpers -------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _check(rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed with status {rc} (see ALS_E_* in include/als_hip.h)")
+
+    def slot_bytes(self, k: int) -> int:
+        return int(self.lib.als_partial_slot_bytes(k))
+
+    # -- K1 ------------------------------------------------------------------
+    def row_solve(self, *, k, ld, side, F, bias_self, bias_other, mu, lam, lam_row, lam_b,
+                  lam_b_row, rhs_extra, diag_extra, X_out, bias_out, gram_out, factor_out,
+                  rhs_out, colsum_out, sumr_out, status, tasks, workspace):
+        p = _hip.RowSolveParams()
+        p.k, p.ld, p.nrows = k, ld, side.nrows
+        p.indptr, p.indices, p.vals = _p(side.indptr), _p(side.indices), _p(side.vals)
+        p.F, p.bias_self, p.bias_other, p.mu = _p(F), _p(bias_self), _p(bias_other), _p(mu)
+        p.lambda_scalar, p.lambda_row = float(lam), _p(lam_row)
+        p.lambda_bias_scalar, p.lambda_bias_row = float(lam_b), _p(lam_b_row)
+        p.rhs_extra, p.diag_extra = _p(rhs_extra), _p(diag_extra)
+        p.X_out, p.bias_out, p.gram_out, p.factor_out = _p(X_out), _p(bias_out), _p(gram_out), _p(factor_out)
+        p.rhs_out, p.colsum_out, p.sumr_out, p.status = _p(rhs_out), _p(colsum_out), _p(sumr_out), _p(status)
+        p.tasks, p.ntasks = _p(tasks.tasks), tasks.ntasks
+        p.long_rows, p.nlong = _p(tasks.long_rows), tasks.nlong
+        p.workspace = _p(workspace)
+        self._check(self.lib.als_row_solve(C.byref(p), self._stream()), "als_row_solve")
+
+    # -- K2 ------------------------------------------------------------------
+    def gs_level(self, *, k, ld, items, S_ptr, S_idx, S_val, alpha, factor, rhs, colsum, sumr,
+                 indptr, lam_b, lam_b_row, V, bias):
+        p = _hip.GsSweepParams()
+        p.k, p.ld = k, ld
+        p.items, p.nitems = _p(items), items.numel()
+        p.S_ptr, p.S_idx, p.S_val, p.alpha = _p(S_ptr), _p(S_idx), _p(S_val), float(alpha)
+        p.factor, p.rhs, p.colsum, p.sumr = _p(factor), _p(rhs), _p(colsum), _p(sumr)
+        p.indptr, p.lambda_bias_scalar, p.lambda_bias_row = _p(indptr), float(lam_b), _p(lam_b_row)
+        p.V, p.bias = _p(V), _p(bias)
+        self._check(self.lib.als_gs_sweep(C.byref(p), self._stream()), "als_gs_sweep")
+
+    # -- K6 ------------------------------------------------------------------
+    def residual_stats(self, *, k, ld, side, U, Z, b_u, b_i, mu, tasks, out):
+        if tasks.ntasks == 0:
+            out.zero_()
+            return
+        need = 2 * ((tasks.ntasks + 3) // 4)
+        if self._stats_partials is None or self._stats_partials.numel() < need:
+            self._stats_partials = torch.empty(need, dtype=torch.float64, device=self.device)
+        self._check(self.lib.als_residual_stats(
+            k, ld, _p(side.indptr), _p(side.indices), _p(side.vals), _p(U), _p(Z), _p(b_u), _p(b_i),
+            _p(mu), _p(tasks.tasks), tasks.ntasks, _p(self._stats_partials), _p(out), self._stream()),
+            "als_residual_stats")
+
+    def sumsq(self, x: torch.Tensor, out: torch.Tensor):
+        self._check(self.lib.als_sumsq(_p(x), x.numel(), _p(self._sumsq_partials), _p(out),
+                                       self._stream()), "als_sumsq")
+
+    # -- K0 / K7 ---------------------------------------------------------------
+    def compose_z(self, V, X, W, Z):
+        D = 0 if X is None else X.shape[1]
+        self._check(self.lib.als_compose_z(V.shape[0], V.shape[1], D, _p(V), _p(X), _p(W), _p(Z),
+                                           self._stream()), "als_compose_z")
+
+    def predict_at(self, *, k, ld, us, is_, U, Z, b_u, b_i, mu, out):
+        self._check(self.lib.als_predict_at(k, ld, us.numel(), _p(us), _p(is_), _p(U), _p(Z), _p(b_u),
+                                            _p(b_i), _p(mu), _p(out), self._stream()), "als_predict_at")
+
+    def predict_dense(self, *, k, ld, m, n, U, Z, b_u, b_i, mu, out):
+        self._check(self.lib.als_predict_dense(k, ld, m, n, _p(U), _p(Z), _p(b_u), _p(b_i), _p(mu),
+                                               _p(out), self._stream()), "als_predict_dense")

@@ -1,0 +1,161 @@
+// Device-side helpers shared by the gfx950 ALS kernels.
+//
+// Layout vocabulary ("Data layout"):
+//   KB    number of 16-column factor blocks, ld = KP = 16*KB
+//   lane  = (c, q): c = lane & 15 (position in a block), q = lane >> 4
+//   perm  factor column `col` sits at perm position 16*(col % KB) + col / KB,
+//         so that lane c's contiguous KB floats F[row][KB*c .. KB*c+KB-1] are
+//         exactly "position c of every block": one coalesced vector load per
+//         lane feeds all MFMA operands with no LDS staging and no shuffles.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define ALS_EPS 1e-10f
+
+__device__ __forceinline__ float readlane_f(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+__device__ __forceinline__ float bperm_f(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ int bperm_i(int v, int src_lane) {
+    return __builtin_amdgcn_ds_bpermute(src_lane << 2, v);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// All LDS traffic of one wave is ordered by the hardware; this stops the
+// compiler from moving LDS accesses across a cross-lane hand-off and waits for
+// outstanding DS operations.  Waves of a workgroup never exchange data, so no
+// s_barrier is involved (waves run different trip counts).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// perm position p -> actual factor column
+template <int KB>
+__device__ __forceinline__ int perm_to_col(int p) { return KB * (p & 15) + (p >> 4); }
+
+// Load the KB contiguous floats of lane c (16-byte aligned when KB % 4 == 0).
+template <int KB>
+__device__ __forceinline__ void load_frow(const float* __restrict__ p, float (&f)[KB]) {
+    if constexpr (KB % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < KB / 4; ++j) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * j);
+            f[4 * j] = v.x; f[4 * j + 1] = v.y; f[4 * j + 2] = v.z; f[4 * j + 3] = v.w;
+        }
+    } else if constexpr (KB % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < KB / 2; ++j) {
+            f32x2 v = *reinterpret_cast<const f32x2*>(p + 2 * j);
+            f[2 * j] = v.x; f[2 * j + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < KB; ++j) f[j] = p[j];
+    }
+}
+
+template <int KB>
+struct KCfg {
+    static constexpr int KP = 16 * KB;
+    static constexpr int LD = KP + 1;                 // odd: row and column LDS walks conflict-free
+    static constexpr int NACC = KB * (KB + 1) / 2;    // upper 16x16 blocks
+    static constexpr int NR = (KP + 63) / 64;         // matrix rows owned per lane
+    static constexpr int LDS_FLOATS = KP * LD + 3 * KP;   // matrix + rhs + colsum + dinv
+    // waves per workgroup chosen so that two workgroups fit a CU's 160 KiB
+    static constexpr int WPW = (KB <= 4) ? 4 : (KB <= 6 ? 2 : 1);
+    static constexpr int SLOT_ITEMS = NACC * 4 + 2 * KB + 1;  // per-lane floats of a partial
+    // gather steps (4 ratings each) staged in registers at a time
+    static constexpr int GS = (KB <= 4) ? 16 : (KB <= 8 ? 8 : 4);
+};
+
+// ---------------------------------------------------------------------------
+// triangular solves  (L L^T) x = b  for one wave
+// ---------------------------------------------------------------------------
+// KP <= 64, everything in registers.  Lane i holds column i of the symmetric
+// completion of L:  a[p] = L[i][p] (p < i),  a[p] = L[p][i] (p > i), and
+// di = 1/L[i][i].  rb is b[i] on entry; returns x[i].  Both sweeps keep the
+// right-hand side pre-scaled by di so that each of the 2*KP dependent steps is
+// one v_readlane + one v_fma.
+template <int KP>
+__device__ __forceinline__ float solve_regs(const float (&a)[KP], float di, float rb, int lane) {
+    float rs = rb * di;
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        const float yj = readlane_f(rs, j);
+        const float cf = (lane > j) ? a[j] * di : 0.f;
+        rs = fmaf(-cf, yj, rs);
+    }
+    rs *= di;   // lane j now holds y_j; rescale for the transposed sweep
+#pragma unroll
+    for (int i = KP - 1; i >= 0; --i) {
+        const float xi = readlane_f(rs, i);
+        const float cf = (lane < i) ? a[i] * di : 0.f;
+        rs = fmaf(-cf, xi, rs);
+    }
+    return rs;
+}
+
+// any KP, L in LDS: Al[j*LD + i] = L[i][j] (i > j), dinv[j] = 1/L[j][j].
+// vec[] (LDS, perm space) holds b on entry and x on exit.
+template <int KB>
+__device__ __forceinline__ void solve_lds(const float* __restrict__ Al, const float* __restrict__ dinv,
+                                          float* __restrict__ vec, int lane) {
+    constexpr int KP = KCfg<KB>::KP, LD = KCfg<KB>::LD, NR = KCfg<KB>::NR;
+    float rb[NR], di[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        const int i = lane + 64 * rr;
+        rb[rr] = (i < KP) ? vec[i] : 0.f;
+        di[rr] = (i < KP) ? dinv[i] : 0.f;
+    }
+    for (int j = 0; j < KP; ++j) {            // L y = b
+        float yj = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            const float cand = readlane_f(rb[rr] * di[rr], j & 63);
+            if ((j >> 6) == rr) yj = cand;
+        }
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            const int i = lane + 64 * rr;
+            if (i == j) rb[rr] = yj;
+            else if (i > j && i < KP) rb[rr] = fmaf(-Al[j * LD + i], yj, rb[rr]);
+        }
+    }
+    for (int ii = KP - 1; ii >= 0; --ii) {    // L^T x = y
+        float xi = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            const float cand = readlane_f(rb[rr] * di[rr], ii & 63);
+            if ((ii >> 6) == rr) xi = cand;
+        }
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            const int j = lane + 64 * rr;
+            if (j == ii) rb[rr] = xi;
+            else if (j < ii) rb[rr] = fmaf(-Al[j * LD + ii], xi, rb[rr]);
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        const int i = lane + 64 * rr;
+        if (i < KP) vec[i] = rb[rr];
+    }
+    wave_lds_sync();
+}

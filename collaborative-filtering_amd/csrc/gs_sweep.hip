@@ -1,0 +1,142 @@
+// K2: one dependency level of the Gauss-Seidel Laplacian sweep.
+//
+// Replaces the graph part of the reference item loop (scripts/als.py:453-461,
+// 464-466).  The reference reads `self.V` live, so item i sees the rows j < i
+// already updated in this sweep.  Only that cheap tail is sequential: the Gram,
+// the right-hand side U_i^T r_i and the Cholesky factor do not depend on V and
+// were produced for all items in parallel by als_row_solve (factor-only mode).
+// Items of one level ("Level schedule") do not neighbour each
+// other, so one launch solves a whole level with one wavefront per item:
+//   b = rhs_i + alpha * sum_j S_ij V_j ;  V_i = (L L^T)^{-1} b ;  bias update.
+#include "als_device.hpp"
+#include "als_hip.h"
+
+namespace {
+
+template <int KB>
+__global__ __launch_bounds__(64 * KCfg<KB>::WPW)
+void k_gs_level(const als_gs_sweep_params P) {
+    using C = KCfg<KB>;
+    constexpr int KP = C::KP, LD = C::LD, NR = C::NR;
+    __shared__ float lds_all[(KB <= 4) ? 1 : C::WPW * C::LDS_FLOATS];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t tid = (int64_t)blockIdx.x * C::WPW + wave;
+    if (tid >= P.nitems) return;
+    const int item = P.items[tid];
+    const int64_t i64 = item;
+    const int64_t s0 = P.S_ptr[item], s1 = P.S_ptr[item + 1];
+    const float nnz = (float)(P.indptr[item + 1] - P.indptr[item]);
+    const float lb = P.lambda_bias_row ? P.lambda_bias_row[item] : P.lambda_bias_scalar;
+    const float* M = P.factor + i64 * KP * KP;
+
+    // graph term in perm space: lane (+64*rr) <-> perm position
+    int col[NR];
+    float g[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        const int p = min(lane + 64 * rr, KP - 1);
+        col[rr] = perm_to_col<KB>(p);
+        g[rr] = 0.f;
+    }
+    for (int64_t t = s0; t < s1; t += 8) {
+        float sv[8];
+        int sj[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = t + e < s1;
+            sj[e] = ok ? P.S_idx[t + e] : item;
+            sv[e] = ok ? P.S_val[t + e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr)
+                g[rr] = fmaf(sv[e], P.V[(int64_t)sj[e] * P.ld + col[rr]], g[rr]);
+    }
+
+    if constexpr (KB <= 4) {
+        float a[KP];
+        const int i = min(lane, KP - 1);
+#pragma unroll
+        for (int p = 0; p < KP; ++p) a[p] = M[p * KP + i];
+        const float di = M[i * KP + i];
+        const float rb = P.rhs[i64 * KP + i] + P.alpha * g[0];
+        const float x = solve_regs<KP>(a, di, rb, lane);
+        float dot = 0.f;
+        if (lane < KP) {
+            P.V[i64 * P.ld + col[0]] = x;
+            dot = P.colsum[i64 * KP + lane] * x;
+        }
+        dot = wave_sum(dot);
+        if (lane == 0) P.bias[item] = (P.sumr[item] - dot) / (nnz + lb + ALS_EPS);
+    } else {
+        float* Al = lds_all + wave * C::LDS_FLOATS;
+        float* vec = Al + KP * LD;
+        float* dinv = vec + 2 * KP;
+        for (int p = 0; p < KP; ++p)
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                const int i = lane + 64 * rr;
+                if (i < KP) {
+                    const float v = M[p * KP + i];
+                    if (i > p) Al[p * LD + i] = v;          // L[i][p]
+                    else if (i == p) dinv[i] = v;
+                }
+            }
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            const int i = lane + 64 * rr;
+            if (i < KP) vec[i] = P.rhs[i64 * KP + i] + P.alpha * g[rr];
+        }
+        wave_lds_sync();
+        solve_lds<KB>(Al, dinv, vec, lane);
+        float dot = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            const int i = lane + 64 * rr;
+            if (i < KP) {
+                const float x = vec[i];
+                P.V[i64 * P.ld + col[rr]] = x;
+                dot = fmaf(P.colsum[i64 * KP + i], x, dot);
+            }
+        }
+        dot = wave_sum(dot);
+        if (lane == 0) P.bias[item] = (P.sumr[item] - dot) / (nnz + lb + ALS_EPS);
+    }
+}
+
+template <int KB>
+int launch_gs(const als_gs_sweep_params* p, hipStream_t st) {
+    using C = KCfg<KB>;
+    if (p->nitems <= 0) return 0;
+    const unsigned grid = (unsigned)((p->nitems + C::WPW - 1) / C::WPW);
+    hipLaunchKernelGGL(k_gs_level<KB>, dim3(grid), dim3(64 * C::WPW), 0, st, *p);
+    return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int als_gs_sweep(const als_gs_sweep_params* p, void* stream) {
+    if (!p) return ALS_E_BADARG;
+    const int ld = als_padded_k(p->k);
+    if (ld < 0) return ALS_E_BADK;
+    if (p->ld != ld || p->nitems < 0 || !p->S_ptr || !p->factor || !p->rhs || !p->colsum ||
+        !p->sumr || !p->indptr || !p->V || !p->bias)
+        return ALS_E_BADARG;
+    if (p->nitems > 0 && !p->items) return ALS_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (ld / 16) {
+        case 1: return launch_gs<1>(p, st);
+        case 2: return launch_gs<2>(p, st);
+        case 3: return launch_gs<3>(p, st);
+        case 4: return launch_gs<4>(p, st);
+        case 5: return launch_gs<5>(p, st);
+        case 6: return launch_gs<6>(p, st);
+        case 7: return launch_gs<7>(p, st);
+        case 8: return launch_gs<8>(p, st);
+        case 9: return launch_gs<9>(p, st);
+        case 10: return launch_gs<10>(p, st);
+    }
+    return ALS_E_BADK;
+}

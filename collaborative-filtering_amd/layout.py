@@ -1,0 +1,194 @@
+"""Host-side (numpy) preparation of the HBM-resident data structures.
+
+Everything here runs once per `fit`, before the timed loop: COO -> CSR/CSC,
+the row-task lists consumed by `als_row_solve` (include/als_hip.h), the
+perm-space index map, and the Gauss-Seidel level schedule of the Laplacian
+sweep.  It restates the reference's adjacency construction
+(scripts/als.py:332-340) on sparse input; nothing is dense m x n.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+SPLIT_CHUNK = 4096          # == ALS_SPLIT_CHUNK in include/als_hip.h
+
+
+def padded_k(k: int) -> int:
+    if k < 1 or k > 160:
+        raise ValueError(f"n_factors={k} outside the supported range 1..160")
+    return 16 * ((k + 15) // 16)
+
+
+def perm_of_col(k: int) -> np.ndarray:
+    """perm-space position of every storage column (length ld)."""
+    ld = padded_k(k)
+    kb = ld // 16
+    c = np.arange(ld)
+    return (16 * (c % kb) + c // kb).astype(np.int64)
+
+
+@dataclass
+class SparseSide:
+    """One orientation of the rating matrix (CSR by user or CSC by item)."""
+    nrows: int
+    ncols: int
+    indptr: np.ndarray      # int64 [nrows+1]
+    indices: np.ndarray     # int32 [nnz]
+    vals: np.ndarray        # float32 [nnz]
+
+
+def coo_to_sides(rows, cols, vals, shape) -> Tuple[SparseSide, SparseSide]:
+    """Row-major-sorted CSR (users) and column-major-sorted CSC (items).
+
+    Index order inside a row / column is ascending, as `np.flatnonzero` yields
+    in the reference (scripts/als.py:338-339).
+    """
+    m, n = int(shape[0]), int(shape[1])
+    rows = np.asarray(rows)
+    cols = np.asarray(cols)
+    vals = np.asarray(vals, dtype=np.float32)
+    if rows.size:
+        if rows.min() < 0 or rows.max() >= m or cols.min() < 0 or cols.max() >= n:
+            raise ValueError("rating index outside the matrix shape")
+    key = rows.astype(np.int64) * n + cols.astype(np.int64)
+    order = np.argsort(key, kind="stable")
+    if order.size > 1 and np.any(np.diff(key[order]) == 0):
+        raise ValueError("duplicate (user, item) entries")
+    ru, ri, rv = rows[order], cols[order], vals[order]
+    uptr = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(np.bincount(ru, minlength=m), out=uptr[1:])
+    corder = np.argsort(ri.astype(np.int64) * m + ru.astype(np.int64), kind="stable")
+    iptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(ri, minlength=n), out=iptr[1:])
+    csr = SparseSide(m, n, uptr, ri.astype(np.int32), rv)
+    csc = SparseSide(n, m, iptr, ru[corder].astype(np.int32), rv[corder])
+    return csr, csc
+
+
+def dense_to_coo(R: np.ndarray):
+    """Dense NaN-coded matrix -> COO (scripts/als.py:335,340)."""
+    ru, ri = np.nonzero(~np.isnan(R))
+    return ru, ri, R[ru, ri]
+
+
+@dataclass
+class RowTasks:
+    """Task list of one orientation / one shard (struct als_task, als_long_row)."""
+    tasks: np.ndarray        # int32 [ntasks, 4]  (row, seg, slot, 0)
+    long_rows: np.ndarray    # int32 [nlong, 4]   (row, slot0, nslots, 0)
+    nslots: int
+    nnz: int                 # ratings covered
+
+
+def build_row_tasks(indptr: np.ndarray, row_begin: int = 0, row_end: Optional[int] = None,
+                    chunk: int = SPLIT_CHUNK) -> RowTasks:
+    """Tasks for rows [row_begin, row_end) with at least one rating.
+
+    Rows longer than `chunk` are split into segments whose partial normal
+    equations are summed in segment order by the finishing kernel.  Tasks are
+    ordered longest-first so that the tail of the launch is made of short rows.
+    """
+    row_end = len(indptr) - 1 if row_end is None else row_end
+    counts = np.diff(indptr[row_begin:row_end + 1])
+    rows = np.nonzero(counts > 0)[0]
+    cnt = counts[rows]
+    rows = rows + row_begin
+    nseg = (cnt + chunk - 1) // chunk
+    is_long = nseg > 1
+    # short rows: one task each
+    s_rows, s_len = rows[~is_long], cnt[~is_long]
+    # long rows: nseg tasks each, consecutive slots
+    l_rows, l_nseg, l_cnt = rows[is_long], nseg[is_long], cnt[is_long]
+    slot0 = np.zeros(l_rows.size, dtype=np.int64)
+    if l_rows.size:
+        slot0[1:] = np.cumsum(l_nseg)[:-1]
+    nslots = int(l_nseg.sum())
+    t_row = np.repeat(l_rows, l_nseg)
+    t_seg = (np.arange(nslots) - np.repeat(slot0, l_nseg)).astype(np.int64)
+    t_slot = np.arange(nslots, dtype=np.int64)
+    t_len = np.minimum(chunk, np.repeat(l_cnt, l_nseg) - t_seg * chunk)
+    all_row = np.concatenate([t_row, s_rows])
+    all_seg = np.concatenate([t_seg, np.zeros(s_rows.size, dtype=np.int64)])
+    all_slot = np.concatenate([t_slot, -np.ones(s_rows.size, dtype=np.int64)])
+    all_len = np.concatenate([t_len, s_len])
+    order = np.argsort(-all_len, kind="stable")
+    tasks = np.zeros((all_row.size, 4), dtype=np.int32)
+    tasks[:, 0] = all_row[order]
+    tasks[:, 1] = all_seg[order]
+    tasks[:, 2] = all_slot[order]
+    long_rows = np.zeros((l_rows.size, 4), dtype=np.int32)
+    long_rows[:, 0] = l_rows
+    long_rows[:, 1] = slot0
+    long_rows[:, 2] = l_nseg
+    return RowTasks(tasks, long_rows, nslots, int(cnt.sum()))
+
+
+def shard_bounds(nrows: int, world: int) -> Tuple[int, List[Tuple[int, int]]]:
+    """Equal contiguous row shards: (rows per shard, [(begin, end) per rank])."""
+    per = (nrows + world - 1) // world
+    return per, [(min(r * per, nrows), min((r + 1) * per, nrows)) for r in range(world)]
+
+
+def build_similarity_dense(X: np.ndarray, topk: Optional[int], eps: float) -> np.ndarray:
+    """Item-item cosine top-k graph, symmetrised by max.
+
+    Same numpy call sequence as the reference (scripts/als.py:224-240) so that
+    `argpartition`'s tie order at the top-k boundary (which decides the graph
+    when features are binary) is the reference's.  O(n^2 d): host-side, small
+    n only; larger problems pass a precomputed CSR graph to `fit`.
+    """
+    norms = np.sqrt((X * X).sum(axis=1, keepdims=True)) + eps
+    Xn = X / norms
+    S = Xn @ Xn.T
+    np.fill_diagonal(S, 0.0)
+    if topk is not None and topk < S.shape[0]:
+        for i in range(S.shape[0]):
+            drop = np.argpartition(S[i], -topk)[:-topk]
+            S[i, drop] = 0.0
+    return np.maximum(S, S.T)
+
+
+def dense_graph_to_csr(S: np.ndarray):
+    ri, ci = np.nonzero(S)
+    ptr = np.zeros(S.shape[0] + 1, dtype=np.int64)
+    np.cumsum(np.bincount(ri, minlength=S.shape[0]), out=ptr[1:])
+    return ptr, ci.astype(np.int32), S[ri, ci]
+
+
+@dataclass
+class LevelSchedule:
+    items: np.ndarray        # int32: swept items, grouped by level, ascending id inside
+    offsets: np.ndarray      # int64 [nlevels+1] into items
+
+
+def build_level_schedule(S_ptr: np.ndarray, S_idx: np.ndarray, active: np.ndarray,
+                         begin: int = 0, end: Optional[int] = None) -> LevelSchedule:
+    """Dependency levels of the index-ordered Gauss-Seidel sweep.
+
+    Item i (active = has ratings, begin <= i < end) must run after every
+    neighbour j < i that is itself swept in [begin, end); neighbours j > i
+    must still hold their previous value, which symmetry of S guarantees
+    (j > i neighbour => level(j) > level(i)).  level(i) = 1 + max level of
+    earlier swept neighbours.
+    """
+    n = len(S_ptr) - 1
+    end = n if end is None else end
+    level = np.full(n, -1, dtype=np.int64)
+    for i in range(begin, end):
+        if not active[i]:
+            continue
+        nb = S_idx[S_ptr[i]:S_ptr[i + 1]]
+        nb = nb[(nb < i) & (nb >= begin)]
+        lv = level[nb].max() if nb.size else -1
+        level[i] = lv + 1                      # inactive neighbours carry -1
+    swept = np.nonzero(level >= 0)[0]
+    order = np.lexsort((swept, level[swept]))
+    items = swept[order].astype(np.int32)
+    nlev = int(level.max()) + 1 if swept.size else 0
+    offsets = np.zeros(nlev + 1, dtype=np.int64)
+    if swept.size:
+        np.cumsum(np.bincount(level[swept], minlength=nlev), out=offsets[1:])
+    return LevelSchedule(items, offsets)

@@ -1,0 +1,194 @@
+/*
+ * als_hip.h - C ABI of the MI355X (gfx950) ALS hot path.
+ *
+ * The reference (zhukovanadezhda/collaborative-filtering) has no FFI: its hot
+ * path is the Python method `ALS.fit` (scripts/als.py:300-529) and
+ * `ALS.predict` (scripts/als.py:532-574).  This header is the boundary the
+ * build's Python mirror of that class (collaborative-filtering_amd/als.py)
+ * calls through ctypes; every entry point names the reference lines it
+ * replaces.  See INTEGRATION.md for the binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, scalars; no C++/torch types.
+ *   - every pointer is a DEVICE pointer (HBM) unless it says "host".
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *     nothing synchronises, allocates or frees.
+ *   - return value: 0 ok, negative = argument error (ALS_E_*).
+ *   - factor matrices are row-major fp32 with leading dimension
+ *     ld = als_padded_k(k) (k rounded up to a multiple of 16); the padding
+ *     columns must be zero on input and are written as zero.
+ *   - rating matrices are CSR-like: int64 row pointers, int32 indices, fp32
+ *     values.  The same entry point serves the user step (CSR) and the item
+ *     step (CSC); "row" below means a row of whichever orientation is passed.
+ *   - "perm space": inside the solver a factor column c lives at position
+ *     perm(c) = 16*(c % KB) + c / KB, KB = ld/16.  Outputs documented as
+ *     perm-space use that order; als_perm_index() gives the map.
+ */
+#ifndef ALS_HIP_H
+#define ALS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALS_HIP_VERSION 100
+
+#define ALS_E_BADARG   (-1)
+#define ALS_E_BADK     (-2)   /* k outside 1..ALS_MAX_K */
+#define ALS_E_LAUNCH   (-3)   /* hipGetLastError() != hipSuccess after a launch */
+
+#define ALS_MAX_K 160
+#define ALS_SPLIT_CHUNK 4096  /* ratings per task segment (see als_task) */
+
+/* One unit of row-solve work: ratings [seg*ALS_SPLIT_CHUNK, +len) of `row`.
+ * slot < 0 : the row fits one segment and is solved in place.
+ * slot >= 0: partial normal equations go to workspace slot `slot`; the row is
+ *            completed by the matching als_long_row entry.                  */
+typedef struct als_task {
+    int32_t row;
+    int32_t seg;
+    int32_t slot;
+    int32_t reserved;
+} als_task;
+
+/* A row split over `nslots` consecutive workspace slots starting at `slot0`. */
+typedef struct als_long_row {
+    int32_t row;
+    int32_t slot0;
+    int32_t nslots;
+    int32_t reserved;
+} als_long_row;
+
+int als_version(void);
+int als_padded_k(int k);                       /* ld for k factors            */
+int als_perm_index(int k, int c);              /* perm-space position of col c */
+/* bytes of one partial slot / of the whole workspace for `nslots` slots */
+int64_t als_partial_slot_bytes(int k);
+
+/* ---------------------------------------------------------------------------
+ * als_row_solve - normal-equation build and solve for a set of rows.
+ * Replaces the bodies of the user loop (scripts/als.py:414-433) and the item
+ * loop (scripts/als.py:436-466) incl. cholesky_solve (scripts/helpers.py:5-20).
+ *
+ * For every task row with nnz > 0:
+ *     F_t   = F[indices[t]]                       (gathered factor rows)
+ *     r_t   = vals[t] - (mu + bias_self[row] + bias_other[indices[t]])
+ *     A     = F^T F + (lambda(row) + 1e-10 + diag_extra[row]) I
+ *     b     = F^T r + rhs_extra[row]              (rhs_extra: actual col order)
+ *     x     = A^{-1} b          (Cholesky; x -> X_out[row])
+ *     bias  = sum_t(vals[t] - F_t.x - mu - bias_other[indices[t]])
+ *             / (nnz + lambda_bias(row) + 1e-10)  (-> bias_out[row])
+ * lambda(row) = lambda_row ? lambda_row[row] : lambda_scalar (same for bias).
+ * Rows with nnz == 0 must not appear in the task list (they keep their
+ * previous X/bias, as in the reference).
+ *
+ * Optional outputs
+ *   gram_out   [nrows][ld][ld]  F^T F (no lambda), perm space, upper 16x16
+ *                               blocks valid (lower blocks unspecified).
+ *   rhs_out    [nrows][ld]    F^T r (perm space, without rhs_extra),
+ *   colsum_out [nrows][ld]    sum_t F_t (perm space),
+ *   sumr_out   [nrows]        sum_t(vals[t] - mu - bias_other[indices[t]])
+ *                             (each written when its pointer is non-NULL)
+ *   factor-only mode (factor_out != NULL): nothing is solved; instead
+ *     factor_out [nrows][ld][ld] symmetric completion of the Cholesky factor
+ *                               L (perm space) with 1/L_ii on the diagonal
+ *   is written for als_gs_sweep, which also needs rhs_out/colsum_out/sumr_out.
+ * status: int32[1], must be 0 on entry (host zeroes it); on a non-SPD pivot
+ *   the kernel stores (row + 1) with atomicMax.
+ * workspace: als_partial_slot_bytes(k) * (number of slots referenced by
+ *   tasks) bytes; may be NULL when no task has slot >= 0.
+ * ------------------------------------------------------------------------- */
+typedef struct als_row_solve_params {
+    int32_t k;
+    int32_t ld;                 /* = als_padded_k(k); ld of F, X_out, rhs_extra */
+    int64_t nrows;              /* rows in this orientation (bounds checks only) */
+    const int64_t* indptr;
+    const int32_t* indices;
+    const float*   vals;
+    const float*   F;           /* gathered side factors [ncols][ld] */
+    const float*   bias_self;   /* [nrows], values before this step */
+    const float*   bias_other;  /* [ncols] */
+    const double*  mu;          /* device scalar */
+    float          lambda_scalar;
+    const float*   lambda_row;          /* nullable */
+    float          lambda_bias_scalar;
+    const float*   lambda_bias_row;     /* nullable */
+    const float*   rhs_extra;           /* nullable [nrows][ld] */
+    const float*   diag_extra;          /* nullable [nrows] */
+    float*         X_out;               /* [nrows][ld] */
+    float*         bias_out;            /* [nrows] (may alias bias_self) */
+    float*         gram_out;            /* nullable */
+    float*         factor_out;          /* nullable -> factor-only mode */
+    float*         rhs_out;
+    float*         colsum_out;
+    float*         sumr_out;
+    int32_t*       status;
+    const als_task*     tasks;      int64_t ntasks;
+    const als_long_row* long_rows;  int64_t nlong;
+    void*          workspace;
+} als_row_solve_params;
+
+int als_row_solve(const als_row_solve_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * als_gs_sweep - one level of the Gauss-Seidel Laplacian sweep.
+ * Replaces the graph part of the item loop (scripts/als.py:453-461,464-466):
+ * for each listed item i (all items of one dependency level):
+ *     b = rhs[i] + alpha * sum_j S_ij V[j]        (V read live)
+ *     V[i] = (L L^T)^{-1} b ;  b_i[i] = (sumr[i] - colsum[i].V[i]) / denom
+ * factor/rhs/colsum/sumr come from als_row_solve in factor-only mode.
+ * ------------------------------------------------------------------------- */
+typedef struct als_gs_sweep_params {
+    int32_t k, ld;
+    const int32_t* items;  int64_t nitems;   /* items of this level */
+    const int64_t* S_ptr;  const int32_t* S_idx;  const float* S_val;
+    float alpha;
+    const float* factor;  const float* rhs;  const float* colsum;
+    const float* sumr;
+    const int64_t* indptr;               /* CSC pointers (nnz per item) */
+    float lambda_bias_scalar;  const float* lambda_bias_row;
+    float* V;                            /* [n][ld], updated in place */
+    float* bias;                         /* [n] */
+} als_gs_sweep_params;
+
+int als_gs_sweep(const als_gs_sweep_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * als_residual_stats - replaces scripts/als.py:503-512: one pass over the
+ * ratings (CSR) computing sum(d) and sum(d^2), d = r - (U_u.Z_i + b_u + b_i
+ * + mu_old), in fp64.  out[0]=sum d, out[1]=sum d^2 (device doubles).
+ * partials: scratch of 2*ceil(ntasks/4) doubles.
+ * ------------------------------------------------------------------------- */
+int als_residual_stats(int k, int ld, const int64_t* indptr, const int32_t* indices,
+                       const float* vals, const float* U, const float* Z,
+                       const float* b_u, const float* b_i, const double* mu,
+                       const als_task* tasks, int64_t ntasks,
+                       double* partials, double* out, void* stream);
+
+/* sum of squares of a float array in fp64 (scripts/als.py:514-517 norms).
+ * partials: scratch of als_sumsq_partials() doubles. out: device double. */
+int als_sumsq_partials(void);
+int als_sumsq(const float* x, int64_t n, double* partials, double* out, void* stream);
+
+/* Z = V + X W  (scripts/als.py:262-281); X [n][D] fp32 (all features
+ * concatenated column-wise), W [D][ld] fp32.  D == 0 copies V. */
+int als_compose_z(int64_t n, int ld, int D, const float* V, const float* X,
+                  const float* W, float* Z, void* stream);
+
+/* predictions at (u,i) pairs: out[t] = U_u.Z_i + mu + b_u + b_i
+ * (the only way callers read predict(): scripts/tune_params.py:165-166) */
+int als_predict_at(int k, int ld, int64_t npairs, const int32_t* us, const int32_t* is,
+                   const float* U, const float* Z, const float* b_u, const float* b_i,
+                   const double* mu, float* out, void* stream);
+
+/* dense completion R_hat[m][n] = U Z^T + mu + b_u + b_i (scripts/als.py:574) */
+int als_predict_dense(int k, int ld, int64_t m, int64_t n, const float* U,
+                      const float* Z, const float* b_u, const float* b_i,
+                      const double* mu, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALS_HIP_H */

@@ -1,0 +1,238 @@
+"""T3 (GPU): each C-ABI entry point against numpy on random CSR, incl. degenerate
+rows (nnz = 1, < k, >> k, > ALS_SPLIT_CHUNK so the split/finish path runs) and
+k in {1, 16, 32, 50, 64, 128}.  Calls go through ctypes -> libals_hip.so."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _env():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected (-m gpu) but no ROCm device is visible")
+    from collaborative_filtering_amd import layout
+    from collaborative_filtering_amd.als import _side_to_dev, _tasks_to_dev
+    from collaborative_filtering_amd.backend import HipBackend
+    dev = torch.device("cuda", 0)
+    return torch, layout, _side_to_dev, _tasks_to_dev, HipBackend(dev), dev
+
+
+def _random_side(layout, nrows, ncols, lens, seed):
+    rng = np.random.default_rng(seed)
+    indptr = np.zeros(nrows + 1, dtype=np.int64)
+    indptr[1:] = np.cumsum(lens)
+    idx = np.concatenate([np.sort(rng.choice(ncols, size=l, replace=False)) for l in lens]).astype(np.int32) \
+        if sum(lens) else np.zeros(0, np.int32)
+    vals = (np.round(rng.uniform(0.5, 5.0, size=idx.size) * 2) / 2).astype(np.float32)
+    return layout.SparseSide(nrows, ncols, indptr, idx, vals)
+
+
+def _pad(A, ld):
+    out = np.zeros((A.shape[0], ld), dtype=np.float32)
+    out[:, : A.shape[1]] = A
+    return out
+
+
+@pytest.mark.parametrize("k", [1, 16, 32, 50, 64, 128])
+def test_row_solve_against_numpy(k):
+    torch, layout, side_dev, tasks_dev, be, dev = _env()
+    ncols = 9000
+    lens = [1, 2, 0, k // 2 + 1, k, 3 * k + 5, 700, 0, 4096, 4097, 8200 + k, 33, 64, 65, 5]
+    nrows = len(lens)
+    side = _random_side(layout, nrows, ncols, lens, seed=k)
+    rng = np.random.default_rng(100 + k)
+    ld = layout.padded_k(k)
+    F = rng.normal(scale=0.3, size=(ncols, k))
+    b_self = rng.normal(scale=0.2, size=nrows)
+    b_other = rng.normal(scale=0.2, size=ncols)
+    lam_row = rng.uniform(0.5, 4.0, size=nrows)
+    rhs_extra = rng.normal(scale=0.5, size=(nrows, k))
+    diag_extra = rng.uniform(0.0, 2.0, size=nrows)
+    mu, lam_b = 3.3, 1.7
+    t = layout.build_row_tasks(side.indptr)
+    assert t.nslots > 0 and t.long_rows.shape[0] == 2        # split path is exercised
+    sd, td = side_dev(side, dev), tasks_dev(t, dev)
+    f32 = torch.float32
+    X_out = torch.full((nrows, ld), 7.0, dtype=f32, device=dev)
+    bias_out = torch.full((nrows,), 7.0, dtype=f32, device=dev)
+    gram = torch.zeros(nrows, ld, ld, dtype=f32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(t.nslots * be.slot_bytes(k) // 4, dtype=f32, device=dev)
+    be.row_solve(k=k, ld=ld, side=sd, F=torch.from_numpy(_pad(F, ld)).to(dev),
+                 bias_self=torch.from_numpy(b_self.astype(np.float32)).to(dev),
+                 bias_other=torch.from_numpy(b_other.astype(np.float32)).to(dev),
+                 mu=torch.tensor([mu], dtype=torch.float64, device=dev), lam=0.0,
+                 lam_row=torch.from_numpy(lam_row.astype(np.float32)).to(dev), lam_b=lam_b, lam_b_row=None,
+                 rhs_extra=torch.from_numpy(_pad(rhs_extra, ld)).to(dev),
+                 diag_extra=torch.from_numpy(diag_extra.astype(np.float32)).to(dev),
+                 X_out=X_out, bias_out=bias_out, gram_out=gram, factor_out=None, rhs_out=None,
+                 colsum_out=None, sumr_out=None, status=status, tasks=td, workspace=ws)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    X = X_out.cpu().numpy().astype(np.float64)
+    bias = bias_out.cpu().numpy().astype(np.float64)
+    G = gram.cpu().numpy().astype(np.float64)
+    pos = layout.perm_of_col(k)[:k]
+    F32 = F.astype(np.float32).astype(np.float64)
+    for r in range(nrows):
+        lo, hi = side.indptr[r], side.indptr[r + 1]
+        if hi == lo:                                          # untouched, as in the reference
+            assert np.all(X[r] == 7.0) and bias[r] == 7.0
+            continue
+        idx = side.indices[lo:hi]
+        Fr = F32[idx]
+        vals = side.vals[lo:hi].astype(np.float64)
+        rr = vals - (mu + np.float32(b_self[r]) + b_other.astype(np.float32)[idx])
+        A = Fr.T @ Fr + (np.float32(lam_row[r]) + 1e-10 + np.float32(diag_extra[r])) * np.eye(k)
+        b = Fr.T @ rr + rhs_extra.astype(np.float32)[r]
+        x = np.linalg.solve(A, b)
+        scale = max(np.max(np.abs(x)), 1e-6)
+        np.testing.assert_allclose(X[r, :k], x, rtol=2e-3, atol=2e-4 * scale, err_msg=f"row {r} nnz {hi - lo}")
+        assert np.all(X[r, k:] == 0.0)
+        bref = np.sum(vals - Fr @ x - mu - b_other.astype(np.float32)[idx]) / ((hi - lo) + lam_b + 1e-10)
+        assert abs(bias[r] - bref) <= 2e-4 * max(1.0, abs(bref)), (r, bias[r], bref)
+        Gr = G[r][np.ix_(pos, pos)]
+        Gu = np.triu(Fr.T @ Fr)
+        blk = pos // 16
+        upper_block = blk[:, None] <= blk[None, :]            # documented valid region
+        ref = Fr.T @ Fr
+        np.testing.assert_allclose(Gr[upper_block], ref[upper_block], rtol=1e-4,
+                                   atol=1e-5 * max(np.max(np.abs(ref)), 1e-6))
+
+
+@pytest.mark.parametrize("k", [16, 64, 128])
+def test_factor_mode_and_gs_level(k):
+    """factor-only als_row_solve + als_gs_sweep on one level == direct solve with the graph term."""
+    torch, layout, side_dev, tasks_dev, be, dev = _env()
+    ncols, nrows = 3000, 40
+    rng = np.random.default_rng(7 + k)
+    lens = list(rng.integers(1, 300, size=nrows))
+    lens[3] = 5000
+    side = _random_side(layout, nrows, ncols, lens, seed=3 * k)
+    ld = layout.padded_k(k)
+    F = rng.normal(scale=0.3, size=(ncols, k)).astype(np.float32)
+    Vold = rng.normal(scale=0.3, size=(nrows, k)).astype(np.float32)
+    b_self = rng.normal(scale=0.2, size=nrows).astype(np.float32)
+    b_other = rng.normal(scale=0.2, size=ncols).astype(np.float32)
+    lam_row = rng.uniform(0.5, 4.0, size=nrows).astype(np.float32)
+    mu, lam_b, alpha = 3.1, 2.2, 0.7
+    # a graph whose rows only reference items that are NOT swept in this level (items 20..39)
+    sweep = np.arange(0, 20, dtype=np.int32)
+    S_ptr = np.zeros(nrows + 1, dtype=np.int64)
+    S_idx, S_val = [], []
+    for i in range(nrows):
+        nb = rng.choice(np.arange(20, 40), size=rng.integers(0, 9), replace=False)
+        S_idx.append(np.sort(nb))
+        S_val.append(rng.uniform(0.1, 1.0, size=nb.size))
+        S_ptr[i + 1] = S_ptr[i] + nb.size
+    S_idx = np.concatenate(S_idx).astype(np.int32)
+    S_val = np.concatenate(S_val).astype(np.float32)
+    D = np.array([S_val[S_ptr[i]:S_ptr[i + 1]].sum() for i in range(nrows)], dtype=np.float32)
+    t = layout.build_row_tasks(side.indptr)
+    sd, td = side_dev(side, dev), tasks_dev(t, dev)
+    f32 = torch.float32
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    factor = torch.zeros(nrows * ld * ld, dtype=f32, device=dev)
+    rhs = torch.zeros(nrows, ld, dtype=f32, device=dev)
+    cs = torch.zeros(nrows, ld, dtype=f32, device=dev)
+    sumr = torch.zeros(nrows, dtype=f32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(max(t.nslots, 1) * be.slot_bytes(k) // 4, dtype=f32, device=dev)
+    mu_t = torch.tensor([mu], dtype=torch.float64, device=dev)
+    be.row_solve(k=k, ld=ld, side=sd, F=tt(_pad(F, ld)), bias_self=tt(b_self), bias_other=tt(b_other),
+                 mu=mu_t, lam=0.0, lam_row=tt(lam_row), lam_b=lam_b, lam_b_row=None, rhs_extra=None,
+                 diag_extra=tt(alpha * D), X_out=None, bias_out=None, gram_out=None, factor_out=factor,
+                 rhs_out=rhs, colsum_out=cs, sumr_out=sumr, status=status, tasks=td, workspace=ws)
+    V = tt(_pad(Vold, ld))
+    bias = tt(b_self.copy())
+    be.gs_level(k=k, ld=ld, items=tt(sweep), S_ptr=tt(S_ptr), S_idx=tt(S_idx), S_val=tt(S_val),
+                alpha=alpha, factor=factor, rhs=rhs, colsum=cs, sumr=sumr, indptr=sd.indptr,
+                lam_b=lam_b, lam_b_row=None, V=V, bias=bias)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    Vn = V.cpu().numpy().astype(np.float64)
+    bn = bias.cpu().numpy().astype(np.float64)
+    F64 = F.astype(np.float64)
+    for i in range(nrows):
+        if i >= 20:
+            np.testing.assert_array_equal(Vn[i, :k], Vold[i])        # not swept
+            continue
+        lo, hi = side.indptr[i], side.indptr[i + 1]
+        idx = side.indices[lo:hi]
+        Fr = F64[idx]
+        vals = side.vals[lo:hi].astype(np.float64)
+        rr = vals - (mu + b_self[i] + b_other[idx])
+        A = Fr.T @ Fr + (lam_row[i] + 1e-10 + alpha * D[i]) * np.eye(k)
+        sl = slice(S_ptr[i], S_ptr[i + 1])
+        b = Fr.T @ rr + alpha * (S_val[sl].astype(np.float64) @ Vold[S_idx[sl]].astype(np.float64))
+        x = np.linalg.solve(A, b)
+        np.testing.assert_allclose(Vn[i, :k], x, rtol=2e-3, atol=2e-4 * max(np.max(np.abs(x)), 1e-6))
+        bref = np.sum(vals - Fr @ x - mu - b_other[idx]) / ((hi - lo) + lam_b + 1e-10)
+        assert abs(bn[i] - bref) <= 2e-4 * max(1.0, abs(bref))
+
+
+@pytest.mark.parametrize("k", [1, 16, 50, 64, 128])
+def test_stats_predict_compose(k):
+    torch, layout, side_dev, tasks_dev, be, dev = _env()
+    m, n = 300, 500
+    rng = np.random.default_rng(5 + k)
+    lens = list(rng.integers(0, 120, size=m))
+    lens[7] = 0
+    lens[11] = 450
+    side = _random_side(layout, m, n, lens, seed=k + 1)
+    ld = layout.padded_k(k)
+    U = rng.normal(scale=0.3, size=(m, k)).astype(np.float32)
+    V = rng.normal(scale=0.3, size=(n, k)).astype(np.float32)
+    X = rng.normal(size=(n, 7)).astype(np.float32)
+    W = rng.normal(scale=0.2, size=(7, k)).astype(np.float32)
+    b_u = rng.normal(scale=0.2, size=m).astype(np.float32)
+    b_i = rng.normal(scale=0.2, size=n).astype(np.float32)
+    mu = 3.4
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    Ud, Vd = tt(_pad(U, ld)), tt(_pad(V, ld))
+    Zd = torch.empty_like(Vd)
+    be.compose_z(Vd, tt(X), tt(_pad(W, ld)), Zd)
+    Zref = V.astype(np.float64) + X.astype(np.float64) @ W.astype(np.float64)
+    Z = Zd.cpu().numpy()
+    np.testing.assert_allclose(Z[:, :k], Zref, rtol=1e-5, atol=1e-6)
+    assert np.all(Z[:, k:] == 0)
+    t = layout.build_row_tasks(side.indptr)
+    out = torch.zeros(2, dtype=torch.float64, device=dev)
+    mu_t = torch.tensor([mu], dtype=torch.float64, device=dev)
+    be.residual_stats(k=k, ld=ld, side=side_dev(side, dev), U=Ud, Z=Zd, b_u=tt(b_u), b_i=tt(b_i),
+                      mu=mu_t, tasks=tasks_dev(t, dev), out=out)
+    ru = np.repeat(np.arange(m), np.diff(side.indptr))
+    ri = side.indices
+    Z64 = Z[:, :k].astype(np.float64)
+    d = side.vals - (np.sum(U[ru].astype(np.float64) * Z64[ri], axis=1) + b_u[ru] + b_i[ri] + mu)
+    got = out.cpu().numpy()
+    assert abs(got[0] - d.sum()) <= 1e-4 * max(1.0, abs(d.sum())) + 1e-3
+    assert abs(got[1] - (d ** 2).sum()) <= 1e-5 * (d ** 2).sum()
+    ss = torch.zeros(1, dtype=torch.float64, device=dev)
+    be.sumsq(Ud, ss)
+    assert abs(ss.item() - (U.astype(np.float64) ** 2).sum()) <= 1e-9 * (U.astype(np.float64) ** 2).sum() + 1e-12
+    # predictions
+    flat = rng.choice(m * n, size=1001, replace=False)
+    uu, ii = np.divmod(flat, n)
+    outp = torch.empty(flat.size, dtype=torch.float32, device=dev)
+    be.predict_at(k=k, ld=ld, us=tt(uu.astype(np.int32)), is_=tt(ii.astype(np.int32)), U=Ud, Z=Zd,
+                  b_u=tt(b_u), b_i=tt(b_i), mu=mu_t, out=outp)
+    pref = np.sum(U[uu].astype(np.float64) * Z64[ii], axis=1) + mu + b_u[uu] + b_i[ii]
+    np.testing.assert_allclose(outp.cpu().numpy(), pref, atol=2e-5, rtol=1e-5)
+    dense = torch.empty(m, n, dtype=torch.float32, device=dev)
+    be.predict_dense(k=k, ld=ld, m=m, n=n, U=Ud, Z=Zd, b_u=tt(b_u), b_i=tt(b_i), mu=mu_t, out=dense)
+    dref = U.astype(np.float64) @ Z64.T + mu + b_u[:, None] + b_i[None, :]
+    np.testing.assert_allclose(dense.cpu().numpy(), dref, atol=2e-5, rtol=1e-5)
+
+
+def test_bad_arguments_are_rejected():
+    torch, layout, side_dev, tasks_dev, be, dev = _env()
+    import ctypes as C
+    from collaborative_filtering_amd import _hip
+    lib = _hip.load()
+    assert lib.als_padded_k(0) == -2 and lib.als_padded_k(161) == -2 and lib.als_padded_k(50) == 64
+    p = _hip.RowSolveParams()
+    p.k, p.ld = 64, 48                       # ld does not match k
+    assert lib.als_row_solve(C.byref(p), None) == -1
+    assert lib.als_row_solve(None, None) == -1
