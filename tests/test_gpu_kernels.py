@@ -105,7 +105,7 @@ def test_row_solve_against_numpy(k):
 def test_factor_mode_and_gs_level(k):
     """factor-only als_row_solve + als_gs_sweep on one level == direct solve with the graph term."""
     torch, layout, side_dev, tasks_dev, be, dev = _env()
-    ncols, nrows = 3000, 40
+    ncols, nrows = 6000, 40
     rng = np.random.default_rng(7 + k)
     lens = list(rng.integers(1, 300, size=nrows))
     lens[3] = 5000
