@@ -1,0 +1,331 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ratings/sec per ALS iteration at k=64 (BASELINE.json).
+
+Workload (`config.workload`): BASELINE.json configs[3] - synthetic 1M users x
+100K items, 100M ratings, k=64, bias terms + graph-Laplacian regularisation
+(sparse S, 50 neighbours per item before symmetrisation, alpha = 0.5); inputs
+are generated on the GPU following SURVEY.md section 8(d) and are resident in
+HBM before the timed region.  A "step" is one full ALS iteration: U-step,
+V-step (Gram + factor, Gauss-Seidel sweep), mu / RMSE / norm statistics.
+The problem size is fixed as GPUs are added (users sharded for the U-step,
+items for the V-step, RCCL all-gathers in between): "scaling": "strong".
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+`roofline` for the dominant kernel (als_row_solve's k_row_tasks, timed with
+events on its stream) and `cpu_baseline` (the numpy oracle - a port of the
+reference's CPU path - on a bounded row sample, rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GENRE_RATES = [0.1869, 0.1307, 0.0516, 0.0719, 0.3847, 0.1217, 0.0394, 0.4524, 0.0779, 0.01,
+               0.099, 0.0133, 0.0378, 0.0568, 0.1749, 0.0956, 0.199, 0.0408, 0.0177]
+
+SIZES = {   # name: (m, n, nnz, k)
+    "cfg4": (1_000_000, 100_000, 100_000_000, 64),
+    "cfg4-small": (100_000, 10_000, 5_000_000, 64),       # rehearsal size
+    "tiny": (4_000, 1_500, 150_000, 64),
+}
+
+
+def gen_ratings(dev, m, n, nnz, seed):
+    """Power-law sparsity, planted rank-8 model, half-star values; CSR + CSC on the device."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    cu = torch.cumsum(torch.arange(1, m + 1, device=dev, dtype=torch.float64) ** -0.6, 0)
+    ci = torch.cumsum(torch.arange(1, n + 1, device=dev, dtype=torch.float64) ** -0.9, 0)
+    cu /= cu[-1].clone()
+    ci /= ci[-1].clone()
+    uperm = torch.randperm(m, device=dev, generator=g)
+    iperm = torch.randperm(n, device=dev, generator=g)
+    # every user and every item gets at least one rating
+    au = torch.arange(m, device=dev)
+    ai = torch.arange(n, device=dev)
+    diag = torch.unique(torch.cat([au * n + (au % n), (ai % m) * n + ai]))
+    keys = diag
+    while keys.numel() < nnz:
+        draw = max(int(1.15 * (nnz - keys.numel())), 1 << 16)
+        u = uperm[torch.searchsorted(cu, torch.rand(draw, device=dev, dtype=torch.float64, generator=g)).clamp_(max=m - 1)]
+        i = iperm[torch.searchsorted(ci, torch.rand(draw, device=dev, dtype=torch.float64, generator=g)).clamp_(max=n - 1)]
+        keys = torch.unique(torch.cat([keys, u * n + i]))
+        del u, i
+    excess = keys.numel() - nnz
+    if excess > 0:
+        is_diag = torch.isin(keys, diag)
+        cand = torch.nonzero(~is_diag).squeeze(1)
+        drop = cand[torch.randperm(cand.numel(), device=dev, generator=g)[:excess]]
+        keep = torch.ones(keys.numel(), dtype=torch.bool, device=dev)
+        keep[drop] = False
+        keys = keys[keep]
+        del is_diag, cand, drop, keep
+    u = torch.div(keys, n, rounding_mode="floor")
+    i = keys - u * n
+    us = torch.randn(m, 8, device=dev, generator=g) * 0.5
+    vs = torch.randn(n, 8, device=dev, generator=g) * 0.5
+    raw = 3.5 + (us[u] * vs[i]).sum(1) + 0.5 * torch.randn(keys.numel(), device=dev, generator=g)
+    vals = (torch.round(raw * 2.0) / 2.0).clamp_(0.5, 5.0).to(torch.float32)
+    del raw, us, vs
+    uptr = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+    uptr[1:] = torch.cumsum(torch.bincount(u, minlength=m), 0)
+    csr = (uptr, i.to(torch.int32), vals)
+    order = torch.argsort(i * m + u)
+    iptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    iptr[1:] = torch.cumsum(torch.bincount(i, minlength=n), 0)
+    csc = (iptr, u[order].to(torch.int32), vals[order])
+    return csr, csc
+
+
+def gen_graph(dev, n, seed, topk=50, ncand=512):
+    """Sparse item graph: each item keeps its `topk` genre-cosine neighbours among `ncand`
+    random candidates; symmetrised by max; zero similarities are not edges."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    rates = torch.tensor(GENRE_RATES, device=dev)
+    G = (torch.rand(n, 19, device=dev, generator=g) < rates).to(torch.float32)
+    G = G / torch.sqrt((G * G).sum(1, keepdim=True)).clamp_min(1e-8)
+    ncand = min(ncand, n - 1)
+    topk = min(topk, ncand)
+    rows, cols, vals = [], [], []
+    step = 8192
+    for b in range(0, n, step):
+        e = min(b + step, n)
+        cand = torch.randint(0, n, (e - b, ncand), device=dev, generator=g)
+        sims = torch.einsum("bd,bcd->bc", G[b:e], G[cand])
+        sims[cand == torch.arange(b, e, device=dev)[:, None]] = 0.0
+        tv, ti = torch.topk(sims, topk, dim=1)
+        rows.append(torch.arange(b, e, device=dev)[:, None].expand(-1, topk).reshape(-1))
+        cols.append(torch.gather(cand, 1, ti).reshape(-1))
+        vals.append(tv.reshape(-1))
+    r, c, v = torch.cat(rows), torch.cat(cols), torch.cat(vals)
+    ok = v > 0
+    r, c, v = r[ok], c[ok], v[ok]
+    key = torch.cat([r * n + c, c * n + r])
+    val = torch.cat([v, v])
+    uk, inv = torch.unique(key, return_inverse=True)
+    sv = torch.zeros(uk.numel(), device=dev).scatter_reduce_(0, inv, val, reduce="amax")
+    sr = torch.div(uk, n, rounding_mode="floor")
+    sc = uk - sr * n
+    ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    ptr[1:] = torch.cumsum(torch.bincount(sr, minlength=n), 0)
+    return ptr, sc.to(torch.int32), sv.to(torch.float32)
+
+
+def cpu_baseline(eng, budget_s=20.0):
+    """The oracle (numpy port of the reference's per-row loops, float64) on a bounded
+    sample of the same workload: the first rows of the U-step and of the V-step that fit
+    the time budget.  ratings/s per iteration = 1 / (s per rating of U-step + of V-step)."""
+    from oracle.als_oracle import OracleALS, OracleConfig, Ratings
+    md = eng.model
+    k = eng.k
+    o = OracleALS(OracleConfig(n_factors=k, n_iters=1, lambda_u=md.lambda_u, lambda_v=md.lambda_v,
+                               lambda_bu=md.lambda_bu, lambda_bi=md.lambda_bi, alpha=md.alpha,
+                               sim={"feature_name": "genres"} if eng.use_graph else None))
+    uptr = eng.csr.indptr.cpu().numpy()
+    iptr = eng.csc.indptr.cpu().numpy()
+    V = eng.V[: eng.n, :k].double().cpu().numpy()
+    b_i = eng.b_i[: eng.n].double().cpu().numpy()
+    mu = float(eng.mu.item())
+    # ---- users: rows [0, su)
+    su = int(np.searchsorted(uptr, 6_000_000))
+    su = max(1, min(su, eng.m))
+    nu = int(uptr[su])
+    rt = Ratings(su, eng.n, None, eng.csr.indices[:nu].cpu().numpy().astype(np.int64),
+                 eng.csr.vals[:nu].double().cpu().numpy(), uptr[: su + 1].copy(), None, None, None)
+    o.mu, o.V, o.b_i = mu, V, b_i
+    o.U = np.zeros((su, k))
+    o.b_u = np.zeros(su)
+    t0 = time.perf_counter()
+    done_u, rows_u = 0, 0
+    for blk in range(0, su, 256):
+        o.user_step(rt, V, rows=range(blk, min(blk + 256, su)))
+        rows_u = min(blk + 256, su)
+        done_u = int(uptr[rows_u])
+        if time.perf_counter() - t0 > budget_s / 2:
+            break
+    tu = time.perf_counter() - t0
+    # ---- items: columns [0, si) with users remapped to a compact range
+    si = int(np.searchsorted(iptr, 6_000_000))
+    si = max(1, min(si, eng.n))
+    ni = int(iptr[si])
+    users = eng.csc.indices[:ni].cpu().numpy().astype(np.int64)
+    uniq, compact = np.unique(users, return_inverse=True)
+    o.U = eng.U[torch.from_numpy(uniq).to(eng.dev), :k].double().cpu().numpy()
+    o.b_u = eng.b_u[torch.from_numpy(uniq).to(eng.dev)].double().cpu().numpy()
+    o.V = V.copy()
+    o.b_i = b_i.copy()
+    rt2 = Ratings(uniq.size, si, None, None, None, None, iptr[: si + 1].copy(), compact,
+                  eng.csc.vals[:ni].double().cpu().numpy())
+    o.lambda_v_i = np.full(eng.n, float(md.lambda_v))
+    o.lambda_bi_i = np.full(eng.n, float(md.lambda_bi))
+    o.use_graph = eng.use_graph
+    if eng.use_graph:
+        o.S_csr = (eng.S_ptr.cpu().numpy(), eng.S_idx.cpu().numpy().astype(np.int64), eng.S_val.cpu().numpy())
+        o.D = (eng.diag_extra[: eng.n] / np.float32(md.alpha)).cpu().numpy()
+    t0 = time.perf_counter()
+    done_i, cols_i = 0, 0
+    for blk in range(0, si, 32):
+        o.item_step(rt2, cols=range(blk, min(blk + 32, si)))
+        cols_i = min(blk + 32, si)
+        done_i = int(iptr[cols_i])
+        if time.perf_counter() - t0 > budget_s / 2:
+            break
+    tv = time.perf_counter() - t0
+    per_rating = tu / max(done_u, 1) + tv / max(done_i, 1)
+    return {"value": 1.0 / per_rating, "unit": "ratings/s per ALS iteration",
+            "cores": 1, "kind": "port",
+            "sample": (f"oracle/als_oracle.py (float64 numpy+scipy per-row loop): U-step over the first "
+                       f"{rows_u} users ({done_u} ratings, {tu:.1f} s) + V-step with Laplacian term over the "
+                       f"first {cols_i} items ({done_i} ratings, {tv:.1f} s); host has {os.cpu_count()} cores, "
+                       f"loop is single-threaded")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", default="cfg4", choices=sorted(SIZES))
+    ap.add_argument("--gs-mode", default=None, choices=[None, "exact", "block"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="debug only; not a valid headline run")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    from collaborative_filtering_amd import ALS, ALSConfig, BiasesConfig, CoreConfig, GraphConfig, GraphSimConfig
+
+    m, n, nnz, k = SIZES[args.size]
+    t_setup = time.perf_counter()
+    # rank 0 generates, everybody receives the same bytes (robust against RNG differences)
+    if rank == 0:
+        csr, csc = gen_ratings(dev, m, n, nnz, seed=1004)
+        S = None if args.no_graph else gen_graph(dev, n, seed=2004)
+    if world > 1:
+        def bc(t, dtype, numel):
+            if rank != 0:
+                t = torch.empty(numel, dtype=dtype, device=dev)
+            dist.broadcast(t, 0)
+            return t
+        meta = torch.tensor([csr[1].numel() if rank == 0 else 0,
+                             (S[1].numel() if (rank == 0 and S is not None) else 0)], device=dev)
+        dist.broadcast(meta, 0)
+        N, NS = int(meta[0]), int(meta[1])
+        csr = tuple(bc(csr[j] if rank == 0 else None, dt, sz) for j, (dt, sz) in
+                    enumerate([(torch.int64, m + 1), (torch.int32, N), (torch.float32, N)]))
+        csc = tuple(bc(csc[j] if rank == 0 else None, dt, sz) for j, (dt, sz) in
+                    enumerate([(torch.int64, n + 1), (torch.int32, N), (torch.float32, N)]))
+        if not args.no_graph:
+            S = tuple(bc(S[j] if rank == 0 else None, dt, sz) for j, (dt, sz) in
+                      enumerate([(torch.int64, n + 1), (torch.int32, NS), (torch.float32, NS)]))
+        else:
+            S = None
+    nnz = int(csr[1].numel())
+
+    n_total = args.warmup + args.steps
+    cfg = ALSConfig(core=CoreConfig(n_factors=k, n_iters=n_total, lambda_u=5.0, lambda_v=6.0, random_state=42),
+                    biases=BiasesConfig(lambda_bu=3.0, lambda_bi=2.0),
+                    graph=(GraphConfig(alpha=0.5, sim=GraphSimConfig(source="precomputed", topk=50))
+                           if S is not None else GraphConfig()))
+    model = ALS(cfg, device=dev, gs_mode=args.gs_mode)
+    eng = model.prepare_csr(csr, csc, (m, n), S=S)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(args.warmup):
+        eng.iteration(it, n_total)
+    barrier()
+    eng.timers = []
+    t0 = time.perf_counter()
+    for it in range(args.warmup, n_total):
+        eng.iteration(it, n_total)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    eng._check_status()
+
+    # per-kernel times from the events recorded on the launch stream
+    phase = {}
+    for name, a, b in eng.timers:
+        phase.setdefault(name, []).append(a.elapsed_time(b))
+    eng.timers = None
+    hist = eng.hist[: n_total].cpu().numpy()
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        # algorithmic work of the row-solve launches of THIS rank:
+        #   flops/rating/half-step = 2k^2 (Gram) + 2k (rhs) + 2k (bias), + k^3/3 + 2k^2 per solved row
+        #   bytes/rating/half-step = 4 idx + 4 val + 4k factor row + 4 bias; + (4k + 12) per row
+        rs_ms = phase.get("row_solve_user", []) + phase.get("row_solve_item", [])
+        nn_u, nn_i = eng.utasks.nnz, eng.itasks.nnz
+        rows_u = eng.ue - eng.ub
+        rows_i = eng.ie - eng.ib
+        fl = (2 * k * k + 4 * k) * (nn_u + nn_i) + (k ** 3 / 3 + 2 * k * k) * (rows_u + rows_i)
+        by = (4 * k + 12) * (nn_u + nn_i) + (4 * k + 12) * (rows_u + rows_i)
+        t_rs = 1e-3 * sum(rs_ms) / args.steps            # seconds per iteration in row-solve launches
+        n_launch = 2
+        roof = {"kernel": "k_row_tasks<KB=4> (als_row_solve; U-step and V-step launches)",
+                "bound": "mfma", "achieved": fl / t_rs / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                "frac": fl / t_rs / 1e12 / 157.3,
+                "avg_launch_ms": 1e3 * t_rs / n_launch,
+                "algorithmic_flops_per_launch": fl / n_launch,
+                "hbm_view": {"achieved_GBps": by / t_rs / 1e9, "peak_GBps": 8000.0,
+                             "frac": by / t_rs / 1e9 / 8000.0, "algorithmic_bytes_per_launch": by / n_launch},
+                "traffic": None}
+        out = {
+            "metric": "ratings/sec per ALS iteration at k=64", "value": nnz / (elapsed / args.steps),
+            "unit": "ratings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.size}: {m} users x {n} items, {nnz} ratings, k={k}, bias + "
+                                   f"graph-Laplacian (alpha=0.5, {0 if S is None else int(S[1].numel())} graph nnz)"
+                                   f" [BASELINE.json configs[3]]",
+                       "gs_mode": getattr(eng, "gs_mode", None), "gs_levels": (len(eng.sched.offsets) - 1)
+                       if eng.use_graph else 0,
+                       "parallelism": f"users/items sharded x{world}, all-gather of factor blocks",
+                       "setup_s": t_setup},
+            "phase_ms_per_step": {kk: sum(v) / args.steps for kk, v in phase.items()},
+            "train_rmse": [float(x) for x in hist[:, 0]],
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(eng)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,11 +53,32 @@ class _TasksDev:
     nnz: int
 
 
-def _side_to_dev(s: layout.SparseSide, device) -> _SideDev:
+def _side_to_dev(s, device) -> _SideDev:
+    if isinstance(s, _SideDev):
+        return _SideDev(s.nrows, s.ncols, s.indptr.to(device), s.indices.to(device), s.vals.to(device))
     return _SideDev(s.nrows, s.ncols,
                     torch.from_numpy(s.indptr).to(device),
                     torch.from_numpy(s.indices).to(device),
                     torch.from_numpy(s.vals).to(device))
+
+
+def _as_side(triple, nrows: int, ncols: int):
+    indptr, indices, vals = triple
+    if isinstance(indptr, torch.Tensor):
+        if indptr.dtype != torch.int64 or indices.dtype != torch.int32 or vals.dtype != torch.float32:
+            raise ValueError("device CSR needs int64 indptr, int32 indices, float32 vals")
+        if indptr.numel() != nrows + 1 or indices.numel() != vals.numel():
+            raise ValueError("inconsistent CSR sizes")
+        return _SideDev(nrows, ncols, indptr.contiguous(), indices.contiguous(), vals.contiguous())
+    return layout.SparseSide(nrows, ncols, np.ascontiguousarray(indptr, dtype=np.int64),
+                             np.ascontiguousarray(indices, dtype=np.int32),
+                             np.ascontiguousarray(vals, dtype=np.float32))
+
+
+def _to_dev(a, device, dtype) -> torch.Tensor:
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=dtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dtype)
 
 
 def _tasks_to_dev(t: layout.RowTasks, device) -> _TasksDev:
@@ -115,7 +136,31 @@ class ALS:
     def fit_coo(self, rows, cols, vals, shape, features: Optional[Dict[str, np.ndarray]] = None,
                 tol: Optional[float] = 1e-3, min_iters: int = 5, verbose: int = 1, *, S=None) -> "ALS":
         """Same as `fit` on COO triplets; nothing dense m x n is ever formed."""
+        csr, csc = layout.coo_to_sides(rows, cols, vals, (int(shape[0]), int(shape[1])))
+        return self._fit_sides(csr, csc, features, tol, min_iters, verbose, S)
+
+    def fit_csr(self, csr, csc, shape, features: Optional[Dict[str, np.ndarray]] = None,
+                tol: Optional[float] = 1e-3, min_iters: int = 5, verbose: int = 1, *, S=None) -> "ALS":
+        """Fit on ratings that are already CSR (by user) + CSC (by item).
+
+        `csr` / `csc` are (indptr int64, indices int32, vals float32) triples of
+        numpy arrays or torch tensors (device tensors are used in place: this is
+        the entry for inputs that are generated or loaded straight into HBM).
+        Indices must be ascending inside every row / column.
+        """
         m, n = int(shape[0]), int(shape[1])
+        return self._fit_sides(_as_side(csr, m, n), _as_side(csc, n, m), features, tol, min_iters,
+                               verbose, S)
+
+    def prepare_csr(self, csr, csc, shape, features: Optional[Dict[str, np.ndarray]] = None, *, S=None):
+        """Upload / lay out everything `fit_csr` would and return the engine without
+        iterating (bench.py times `engine.iteration(it, n_iters)` itself)."""
+        m, n = int(shape[0]), int(shape[1])
+        self._fit_sides(_as_side(csr, m, n), _as_side(csc, n, m), features, None, 0, 0, S, run=False)
+        return self._eng
+
+    def _fit_sides(self, csr, csc, features, tol, min_iters, verbose, S, run: bool = True) -> "ALS":
+        m, n = csr.nrows, csc.nrows
         features = features or {}
         for name, X in features.items():                     # scripts/als.py:346-351
             if X.shape[0] != n:
@@ -131,7 +176,7 @@ class ALS:
         self.S = None
         if (self.alpha > 0.0) and (self.cfg.graph.sim is not None):
             if S is not None:
-                S_csr = (np.asarray(S[0], np.int64), np.asarray(S[1], np.int32), np.asarray(S[2], np.float32))
+                S_csr = tuple(S)
                 self.S = S_csr
             else:
                 X = features.get(self.cfg.graph.sim.feature_name)
@@ -151,8 +196,9 @@ class ALS:
         if backend is None:
             from .backend import HipBackend
             backend = HipBackend(device)
-        csr, csc = layout.coo_to_sides(rows, cols, vals, (m, n))
         self._eng = _Engine(self, csr, csc, features, S_csr, device, backend, self._pg, self._gs_mode)
+        if not run:                         # prepare(): the caller drives the iterations
+            return self
         if verbose > 0:
             logger.info("Starting ALS training: n_factors=%d, n_iters=%d, lambda_u=%s, lambda_v=%s, "
                         "pop_reg_mode=%s, features=%s, lambda_w=%s, random_state=%s, graph_alpha=%s, "
@@ -206,6 +252,7 @@ class _Engine:
         self.k, self.ld = k, layout.padded_k(k)
         self.m, self.n = csr.nrows, csc.nrows
         self.nnz = int(csr.vals.shape[0])
+        self.timers = None              # set to [] to record (name, start, end) events per phase
         self.perm = torch.from_numpy(layout.perm_of_col(k)).to(device)     # storage col -> perm pos
         f32, f64 = torch.float32, torch.float64
 
@@ -220,8 +267,10 @@ class _Engine:
         # --- ratings in HBM
         self.csr = _side_to_dev(csr, device)
         self.csc = _side_to_dev(csc, device)
-        self.utasks = _tasks_to_dev(layout.build_row_tasks(csr.indptr, self.ub, self.ue), device)
-        self.itasks = _tasks_to_dev(layout.build_row_tasks(csc.indptr, self.ib, self.ie), device)
+        uptr_h = self.csr.indptr.cpu().numpy()
+        iptr_h = self.csc.indptr.cpu().numpy()
+        self.utasks = _tasks_to_dev(layout.build_row_tasks(uptr_h, self.ub, self.ue), device)
+        self.itasks = _tasks_to_dev(layout.build_row_tasks(iptr_h, self.ib, self.ie), device)
         nslots = max(self.utasks.nslots, self.itasks.nslots)
         self.workspace = (torch.empty(nslots * backend.slot_bytes(k) // 4, dtype=f32, device=device)
                           if nslots else None)
@@ -229,8 +278,8 @@ class _Engine:
 
         # --- parameters (scripts/als.py:329,360-376): numpy Generator on the host, same draw order
         rng = np.random.default_rng(model.random_state)
-        self.mu = torch.tensor([float(np.mean(csr.vals.astype(np.float64))) if self.nnz else float("nan")],
-                               dtype=f64, device=device)
+        mean0 = float(self.csr.vals.to(f64).mean().item()) if self.nnz else float("nan")   # :360
+        self.mu = torch.tensor([mean0], dtype=f64, device=device)
         U0 = rng.normal(scale=SCALE_FACTOR, size=(self.m, k))
         V0 = rng.normal(scale=SCALE_FACTOR, size=(self.n, k))
         self.U = self._padded(U0, m_pad)
@@ -257,7 +306,7 @@ class _Engine:
             self.Z = self.V                       # Z == V when there are no features
 
         # --- per-item regularisation (scripts/als.py:379-384, 243-259)
-        counts = np.diff(csc.indptr).astype(np.float64)
+        counts = np.diff(iptr_h).astype(np.float64)
         if not model.pop_reg_mode:
             lam_v = np.full(self.n, float(model.lambda_v))
         else:
@@ -269,18 +318,20 @@ class _Engine:
         # --- graph
         self.use_graph = S_csr is not None
         if self.use_graph:
-            ptr, idx, val = S_csr[0], S_csr[1], S_csr[2]
+            self.S_ptr = _to_dev(S_csr[0], device, torch.int64)
+            self.S_idx = _to_dev(S_csr[1], device, torch.int32)
+            self.S_val = _to_dev(S_csr[2], device, f32)
+            ptr = self.S_ptr.cpu().numpy()
+            idx = self.S_idx.cpu().numpy()
             if len(S_csr) > 3:
-                D = S_csr[3]
-            else:
-                D = np.zeros(self.n, dtype=np.float32)
-                np.add.at(D, np.repeat(np.arange(self.n), np.diff(ptr)), val)
-            self.S_ptr = torch.from_numpy(np.ascontiguousarray(ptr)).to(device)
-            self.S_idx = torch.from_numpy(np.ascontiguousarray(idx)).to(device)
-            self.S_val = torch.from_numpy(np.ascontiguousarray(val)).to(device)
-            de = np.zeros(n_pad, dtype=np.float32)
-            de[: self.n] = np.float32(model.alpha) * D.astype(np.float32)
-            self.diag_extra = torch.from_numpy(de).to(device)
+                D = _to_dev(S_csr[3], device, f32)
+            else:                       # D = S.sum(axis=1) in S's dtype (scripts/als.py:357)
+                D = torch.zeros(self.n, dtype=f32, device=device)
+                rows_of = torch.repeat_interleave(torch.arange(self.n, device=device),
+                                                  self.S_ptr[1:] - self.S_ptr[:-1])
+                D.index_add_(0, rows_of, self.S_val)
+            self.diag_extra = torch.zeros(n_pad, dtype=f32, device=device)
+            self.diag_extra[: self.n] = np.float32(model.alpha) * D
             self.gs_mode = gs_mode or ("exact" if self.world == 1 else "block")
             if self.gs_mode not in ("exact", "block"):
                 raise ValueError(f"unknown gs_mode '{self.gs_mode}'")
@@ -335,16 +386,34 @@ class _Engine:
             raise np.linalg.LinAlgError(
                 f"normal equations of row {bad - 1} are not positive definite")   # scripts/helpers.py:19
 
+    def _tick(self, name):
+        """Context manager recording a (name, start, end) event pair on the current stream."""
+        eng = self
+
+        class _T:
+            def __enter__(self_inner):
+                if eng.timers is not None:
+                    self_inner.a = torch.cuda.Event(enable_timing=True)
+                    self_inner.b = torch.cuda.Event(enable_timing=True)
+                    self_inner.a.record()
+
+            def __exit__(self_inner, *exc):
+                if eng.timers is not None:
+                    self_inner.b.record()
+                    eng.timers.append((name, self_inner.a, self_inner.b))
+        return _T()
+
     # ---------------------------------------------------------- half steps
     def user_step(self):
         """scripts/als.py:414-433 on this rank's user shard, then all-gather."""
         md = self.model
-        self.be.row_solve(k=self.k, ld=self.ld, side=self.csr, F=self.Z, bias_self=self.b_u,
-                          bias_other=self.b_i, mu=self.mu, lam=md.lambda_u, lam_row=None,
-                          lam_b=md.lambda_bu, lam_b_row=None, rhs_extra=None, diag_extra=None,
-                          X_out=self.U, bias_out=self.b_u, gram_out=None, factor_out=None,
-                          rhs_out=None, colsum_out=None, sumr_out=None, status=self.status,
-                          tasks=self.utasks, workspace=self.workspace)
+        with self._tick("row_solve_user"):
+            self.be.row_solve(k=self.k, ld=self.ld, side=self.csr, F=self.Z, bias_self=self.b_u,
+                              bias_other=self.b_i, mu=self.mu, lam=md.lambda_u, lam_row=None,
+                              lam_b=md.lambda_bu, lam_b_row=None, rhs_extra=None, diag_extra=None,
+                              X_out=self.U, bias_out=self.b_u, gram_out=None, factor_out=None,
+                              rhs_out=None, colsum_out=None, sumr_out=None, status=self.status,
+                              tasks=self.utasks, workspace=self.workspace)
         self._allgather_rows(self.U, self.u_per)
         self._allgather_rows(self.b_u, self.u_per)
 
@@ -361,15 +430,19 @@ class _Engine:
                       gram_out=self.gram if want_gram else None, status=self.status,
                       tasks=self.itasks, workspace=self.workspace)
         if not self.use_graph:
-            self.be.row_solve(diag_extra=None, X_out=self.V, bias_out=self.b_i, factor_out=None,
-                              rhs_out=self.rhs_out if want_gram else None,
-                              colsum_out=self.colsum_out if want_gram else None, sumr_out=None, **common)
+            with self._tick("row_solve_item"):
+                self.be.row_solve(diag_extra=None, X_out=self.V, bias_out=self.b_i, factor_out=None,
+                                  rhs_out=self.rhs_out if want_gram else None,
+                                  colsum_out=self.colsum_out if want_gram else None, sumr_out=None, **common)
         else:
             # phase A (parallel): Gram, rhs, Cholesky factor of every item of the shard
-            self.be.row_solve(diag_extra=self.diag_extra, X_out=None, bias_out=None, factor_out=self.factor,
-                              rhs_out=self.rhs_out, colsum_out=self.colsum_out, sumr_out=self.sumr, **common)
+            with self._tick("row_solve_item"):
+                self.be.row_solve(diag_extra=self.diag_extra, X_out=None, bias_out=None,
+                                  factor_out=self.factor, rhs_out=self.rhs_out, colsum_out=self.colsum_out,
+                                  sumr_out=self.sumr, **common)
             # phase B (sequential in levels): Gauss-Seidel sweep with live V (:458)
-            self._gs_sweep()
+            with self._tick("gs_sweep"):
+                self._gs_sweep()
         self._allgather_rows(self.V, self.i_per)
         self._allgather_rows(self.b_i, self.i_per)
 
@@ -478,8 +551,9 @@ class _Engine:
         """scripts/als.py:503-517: mu update and the five history series."""
         if self.feat_names:
             self.be.compose_z(self.V, self.Xcat, self.Wcat, self.Z)              # :504
-        self.be.residual_stats(k=self.k, ld=self.ld, side=self.csr, U=self.U, Z=self.Z, b_u=self.b_u,
-                               b_i=self.b_i, mu=self.mu, tasks=self.utasks, out=self.stats)
+        with self._tick("residual_stats"):
+            self.be.residual_stats(k=self.k, ld=self.ld, side=self.csr, U=self.U, Z=self.Z, b_u=self.b_u,
+                                   b_i=self.b_i, mu=self.mu, tasks=self.utasks, out=self.stats)
         self._allreduce(self.stats)
         for j, t in enumerate((self.U, self.V, self.b_u, self.b_i)):
             self.be.sumsq(t, self.ss[j:j + 1])
@@ -491,24 +565,29 @@ class _Engine:
         h[5] = self.mu[0]
 
     # ------------------------------------------------------------------ run
+    def iteration(self, it: int, n_iters: int):
+        """One full ALS iteration (scripts/als.py:408-517), asynchronous on the stream."""
+        md = self.model
+        has_feat = bool(self.feat_names)
+        # Z is current here: stats_step recomposes it after every V / W update
+        self.user_step()
+        do_w = has_feat and ((it % md.update_w_every == 0) or (it == n_iters - 1))       # :468
+        b_i_old = self.b_i.clone() if do_w else None
+        self.item_step(want_gram=do_w)
+        if do_w:
+            self.w_step(b_i_old)
+        self.stats_step(it)
+        self.iters_run = it + 1
+
     def run(self, tol, min_iters, verbose):
         md = self.model
         n_iters = int(md.n_iters)
-        has_feat = bool(self.feat_names)
         rm = md.history["train_rmse"]
         base_len = len(rm)
-        if has_feat:
+        if self.feat_names:
             self.be.compose_z(self.V, self.Xcat, self.Wcat, self.Z)              # :411
         for it in range(n_iters):
-            # Z is current here: stats_step recomposes it after every V / W update
-            self.user_step()
-            do_w = has_feat and ((it % md.update_w_every == 0) or (it == n_iters - 1))   # :468
-            b_i_old = self.b_i.clone() if do_w else None
-            self.item_step(want_gram=do_w)
-            if do_w:
-                self.w_step(b_i_old)
-            self.stats_step(it)
-            self.iters_run = it + 1
+            self.iteration(it, n_iters)
             if tol is not None and it + 1 >= min_iters:                           # :520-523
                 self._check_status()
                 h = self.hist[: it + 1, 0].cpu().numpy()
