@@ -73,12 +73,16 @@ __device__ __forceinline__ void load_frow(const float* __restrict__ p, float (&f
 template <int KB>
 struct KCfg {
     static constexpr int KP = 16 * KB;
-    static constexpr int LD = KP + 1;                 // odd: row and column LDS walks conflict-free
+    // k <= 64: rows 16-byte aligned (uniform ds_read_b128 broadcasts, lane-strided b128
+    // row reads are conflict-free at LD = KP + 4); k > 64: odd stride for column walks
+    static constexpr int LD = (KB <= 4) ? KP + 4 : KP + 1;
     static constexpr int NACC = KB * (KB + 1) / 2;    // upper 16x16 blocks
     static constexpr int NR = (KP + 63) / 64;         // matrix rows owned per lane
     static constexpr int LDS_FLOATS = KP * LD + 3 * KP;   // matrix + rhs + colsum + dinv
     // waves per workgroup chosen so that two workgroups fit a CU's 160 KiB
     static constexpr int WPW = (KB <= 4) ? 4 : (KB <= 6 ? 2 : 1);
+    // minimum waves per SIMD asked of the register allocator (k <= 64: two workgroups per CU)
+    static constexpr int MINW = (KB <= 4) ? 2 : 1;
     static constexpr int SLOT_ITEMS = NACC * 4 + 2 * KB + 1;  // per-lane floats of a partial
     // gather steps (4 ratings each) staged in registers at a time
     static constexpr int GS = (KB <= 4) ? 16 : (KB <= 8 ? 8 : 4);

@@ -146,14 +146,18 @@ __device__ __forceinline__ void add_partial(RowAcc<KB>& A, const float* __restri
 //   dinv[j]      = 1 / L[j][j]
 // returns false if a pivot was not positive.
 // ---------------------------------------------------------------------------
-// KP <= 64: lane i keeps row i of the trailing matrix in registers; columns are
-// broadcast with v_readlane.  Fully unrolled (static register indices).  On
-// exit a[] is lane i's column of the symmetric completion of L (what
-// solve_regs wants) and di = 1/L[i][i]; L's columns are also left in LDS.
+// KP <= 64: lane i keeps row i of the trailing matrix in registers (fully
+// unrolled, static register indices).  Column j of L is published once to LDS
+// (row j of Al - the layout the callers want anyway) and the rank-1 update
+// reads it back as wave-uniform ds_read_b128 broadcasts: 4 multipliers per DS
+// instruction, no SGPR traffic.  Only the pivot of the next step travels by
+// v_readlane.  On exit a[] is lane i's column of the symmetric completion of L
+// (what solve_regs wants) and di = 1/L[i][i].
 template <int KB>
 __device__ __forceinline__ bool chol_regs(float* __restrict__ Al, int lane,
                                           float (&a)[KCfg<KB>::KP], float& di) {
     constexpr int KP = KCfg<KB>::KP, LD = KCfg<KB>::LD;
+    static_assert(LD % 4 == 0, "uniform b128 reads need 16-byte aligned rows");
     const int i = min(lane, KP - 1);
 #pragma unroll
     for (int p = 0; p < KP; ++p) a[p] = (p <= lane) ? Al[p * LD + i] : 0.f;   // A[p][i], p <= i (upper)
@@ -164,19 +168,34 @@ __device__ __forceinline__ bool chol_regs(float* __restrict__ Al, int lane,
     for (int j = 0; j < KP; ++j) {
         const float d = readlane_f(a[j], j);
         spd = spd && (d > 0.f);
-        const float inv = 1.0f / sqrtf(d);
-        const float lij = a[j] * inv;                 // L[i][j] for lanes i >= j
+        float inv = __builtin_amdgcn_rsqf(d);
+        inv = inv * fmaf(-0.5f * d * inv, inv, 1.5f);     // one Newton step: <= 1 ulp
+        const float lij = a[j] * inv;                     // L[i][j] for lanes i >= j
         a[j] = lij;
         if (lane == j) di = inv;
-        if (lane > j && lane < KP) Al[j * LD + lane] = lij;
+        if (lane < KP) Al[j * LD + lane] = lij;           // lanes < j store zeros/unused upper part
+        if (j + 1 < KP) {
+            // the next pivot column does not wait for the LDS round trip
+            a[j + 1] = fmaf(-lij, readlane_f(lij, j + 1), a[j + 1]);
 #pragma unroll
-        for (int cidx = j + 1; cidx < KP; ++cidx)
-            a[cidx] = fmaf(-lij, readlane_f(lij, cidx), a[cidx]);
+            for (int g4 = (j + 2) / 4; g4 < KP / 4; ++g4) {
+                const f32x4 lc = *reinterpret_cast<const f32x4*>(Al + j * LD + 4 * g4);   // uniform address
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int cidx = 4 * g4 + e;
+                    if (cidx > j + 1) a[cidx] = fmaf(-lij, lc[e], a[cidx]);
+                }
+            }
+        }
     }
     wave_lds_sync();
 #pragma unroll
-    for (int p = 0; p < KP; ++p)
-        if (p > lane) a[p] = Al[i * LD + p];          // L[p][i]
+    for (int g4 = 0; g4 < KP / 4; ++g4) {
+        const f32x4 lt = *reinterpret_cast<const f32x4*>(Al + i * LD + 4 * g4);            // L[p][i], p > i
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * g4 + e > lane) a[4 * g4 + e] = lt[e];
+    }
     return spd;
 }
 
@@ -354,7 +373,7 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
 }
 
 template <int KB>
-__global__ __launch_bounds__(64 * KCfg<KB>::WPW)
+__global__ __launch_bounds__(64 * KCfg<KB>::WPW, KCfg<KB>::MINW)
 void k_row_tasks(const als_row_solve_params P) {
     using C = KCfg<KB>;
     __shared__ float lds_all[C::WPW * C::LDS_FLOATS];
@@ -381,7 +400,7 @@ void k_row_tasks(const als_row_solve_params P) {
 }
 
 template <int KB>
-__global__ __launch_bounds__(64 * KCfg<KB>::WPW)
+__global__ __launch_bounds__(64 * KCfg<KB>::WPW, KCfg<KB>::MINW)
 void k_row_long(const als_row_solve_params P) {
     using C = KCfg<KB>;
     __shared__ float lds_all[C::WPW * C::LDS_FLOATS];
