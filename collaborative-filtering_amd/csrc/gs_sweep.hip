@@ -39,34 +39,49 @@ void k_gs_level(const als_gs_sweep_params P) {
         col[rr] = perm_to_col<KB>(p);
         g[rr] = 0.f;
     }
-    for (int64_t t = s0; t < s1; t += 8) {
-        float sv[8];
-        int sj[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bool ok = t + e < s1;
-            sj[e] = ok ? P.S_idx[t + e] : item;
-            sv[e] = ok ? P.S_val[t + e] : 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-#pragma unroll
-            for (int rr = 0; rr < NR; ++rr)
-                g[rr] = fmaf(sv[e], P.V[(int64_t)sj[e] * P.ld + col[rr]], g[rr]);
-    }
-
+    // k <= 64: the factor column of this lane (16 KB per item, independent of V) is
+    // requested first so that it streams in underneath the neighbour gather
+    constexpr int KPR = (KB <= 4) ? KP : 1;
+    float a[KPR];
+    float di = 0.f, rhs_i = 0.f, cs_i = 0.f;
     if constexpr (KB <= 4) {
-        float a[KP];
         const int i = min(lane, KP - 1);
 #pragma unroll
         for (int p = 0; p < KP; ++p) a[p] = M[p * KP + i];
-        const float di = M[i * KP + i];
-        const float rb = P.rhs[i64 * KP + i] + P.alpha * g[0];
+        di = M[i * KP + i];
+        rhs_i = P.rhs[i64 * KP + i];
+        cs_i = P.colsum[i64 * KP + i];
+    }
+    // neighbours: one coalesced pass loads 64 (index, weight) pairs, lane per neighbour;
+    // the V rows are then gathered 16 at a time so that 16 row loads are in flight
+    for (int64_t t0 = s0; t0 < s1; t0 += 64) {
+        const int nn = (int)min((int64_t)64, s1 - t0);
+        const int sj_l = (lane < nn) ? P.S_idx[t0 + lane] : item;
+        const float sv_l = (lane < nn) ? P.S_val[t0 + lane] : 0.f;
+        for (int e0 = 0; e0 < nn; e0 += 16) {
+            float vv[16][NR];
+            float sv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int sj = __shfl(sj_l, e0 + e, 64);            // lanes >= nn carry (item, 0)
+                sv[e] = __shfl(sv_l, e0 + e, 64);
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) vv[e][rr] = P.V[(int64_t)sj * P.ld + col[rr]];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) g[rr] = fmaf(sv[e], vv[e][rr], g[rr]);
+        }
+    }
+
+    if constexpr (KB <= 4) {
+        const float rb = rhs_i + P.alpha * g[0];
         const float x = solve_regs<KP>(a, di, rb, lane);
         float dot = 0.f;
         if (lane < KP) {
             P.V[i64 * P.ld + col[0]] = x;
-            dot = P.colsum[i64 * KP + lane] * x;
+            dot = cs_i * x;
         }
         dot = wave_sum(dot);
         if (lane == 0) P.bias[item] = (P.sumr[item] - dot) / (nnz + lb + ALS_EPS);

@@ -146,13 +146,59 @@ __device__ __forceinline__ void add_partial(RowAcc<KB>& A, const float* __restri
 //   dinv[j]      = 1 / L[j][j]
 // returns false if a pivot was not positive.
 // ---------------------------------------------------------------------------
-// KP <= 64: lane i keeps row i of the trailing matrix in registers (fully
-// unrolled, static register indices).  Column j of L is published once to LDS
-// (row j of Al - the layout the callers want anyway) and the rank-1 update
-// reads it back as wave-uniform ds_read_b128 broadcasts: 4 multipliers per DS
-// instruction, no SGPR traffic.  Only the pivot of the next step travels by
-// v_readlane.  On exit a[] is lane i's column of the symmetric completion of L
-// (what solve_regs wants) and di = 1/L[i][i].
+// KP <= 64: lane i keeps row i of the trailing matrix in registers (static
+// register indices: the column loop is unrolled through templates).  Column j
+// of L is published once to LDS (row j of Al - the layout the callers want
+// anyway) and the rank-1 update reads it back as wave-uniform ds_read_b128
+// broadcasts: 4 multipliers per DS instruction, no SGPR traffic.  Only the
+// pivot of the next step travels by v_readlane.
+template <int KB, int J>
+__device__ __forceinline__ void chol_step(float* __restrict__ Al, int lane, float (&a)[KCfg<KB>::KP],
+                                          float& di, bool& spd) {
+    constexpr int KP = KCfg<KB>::KP, LD = KCfg<KB>::LD;
+    const float d = readlane_f(a[J], J);
+    spd = spd && (d > 0.f);
+    float inv = __builtin_amdgcn_rsqf(d);
+    inv = inv * fmaf(-0.5f * d * inv, inv, 1.5f);     // one Newton step: <= 1 ulp
+    const float lij = a[J] * inv;                     // L[i][J] for lanes i >= J
+    a[J] = lij;
+    if (lane == J) di = inv;
+    if (lane < KP) Al[J * LD + lane] = lij;           // lanes < J store the unused upper part
+    if constexpr (J + 1 < KP) {
+        // the next pivot column does not wait for the LDS round trip
+        a[J + 1] = fmaf(-lij, readlane_f(lij, J + 1), a[J + 1]);
+        constexpr int G0 = (J + 2) / 4, NG = KP / 4 - G0;
+        if constexpr (NG > 0) {
+            // issue every broadcast read of this step back to back, then consume: left to
+            // itself the compiler keeps ~2 reads in flight and exposes the LDS latency per read
+            f32x4 lc[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                lc[g] = *reinterpret_cast<const f32x4*>(Al + J * LD + 4 * (G0 + g));   // uniform address
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int cidx = 4 * (G0 + g) + e;
+                    if (cidx > J + 1) a[cidx] = fmaf(-lij, lc[g][e], a[cidx]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int KB, int J>
+__device__ __forceinline__ void chol_steps(float* __restrict__ Al, int lane, float (&a)[KCfg<KB>::KP],
+                                           float& di, bool& spd) {
+    if constexpr (J < KCfg<KB>::KP) {
+        chol_step<KB, J>(Al, lane, a, di, spd);
+        chol_steps<KB, J + 1>(Al, lane, a, di, spd);
+    }
+}
+
+// On exit a[] is lane i's column of the symmetric completion of L (what
+// solve_regs wants), di = 1/L[i][i], and Al[j*LD + i] = L[i][j].
 template <int KB>
 __device__ __forceinline__ bool chol_regs(float* __restrict__ Al, int lane,
                                           float (&a)[KCfg<KB>::KP], float& di) {
@@ -164,30 +210,7 @@ __device__ __forceinline__ bool chol_regs(float* __restrict__ Al, int lane,
     wave_lds_sync();
     bool spd = true;
     di = 0.f;
-#pragma unroll
-    for (int j = 0; j < KP; ++j) {
-        const float d = readlane_f(a[j], j);
-        spd = spd && (d > 0.f);
-        float inv = __builtin_amdgcn_rsqf(d);
-        inv = inv * fmaf(-0.5f * d * inv, inv, 1.5f);     // one Newton step: <= 1 ulp
-        const float lij = a[j] * inv;                     // L[i][j] for lanes i >= j
-        a[j] = lij;
-        if (lane == j) di = inv;
-        if (lane < KP) Al[j * LD + lane] = lij;           // lanes < j store zeros/unused upper part
-        if (j + 1 < KP) {
-            // the next pivot column does not wait for the LDS round trip
-            a[j + 1] = fmaf(-lij, readlane_f(lij, j + 1), a[j + 1]);
-#pragma unroll
-            for (int g4 = (j + 2) / 4; g4 < KP / 4; ++g4) {
-                const f32x4 lc = *reinterpret_cast<const f32x4*>(Al + j * LD + 4 * g4);   // uniform address
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int cidx = 4 * g4 + e;
-                    if (cidx > j + 1) a[cidx] = fmaf(-lij, lc[e], a[cidx]);
-                }
-            }
-        }
-    }
+    chol_steps<KB, 0>(Al, lane, a, di, spd);
     wave_lds_sync();
 #pragma unroll
     for (int g4 = 0; g4 < KP / 4; ++g4) {
