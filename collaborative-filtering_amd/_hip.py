@@ -25,7 +25,7 @@ _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 class RowSolveParams(C.Structure):
     """struct als_row_solve_params (include/als_hip.h)."""
     _fields_ = [
-        ("k", _i32), ("ld", _i32), ("nrows", _i64),
+        ("k", _i32), ("ld", _i32), ("nrows", _i64), ("F_zero_row", _i32), ("reserved0", _i32),
         ("indptr", _vp), ("indices", _vp), ("vals", _vp), ("F", _vp),
         ("bias_self", _vp), ("bias_other", _vp), ("mu", _vp),
         ("lambda_scalar", _f32), ("lambda_row", _vp),

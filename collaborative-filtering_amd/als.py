@@ -299,7 +299,7 @@ class _Engine:
             self.X64 = {f: torch.from_numpy(np.asarray(features[f], dtype=np.float64)).to(device)
                         for f in self.feat_names}
             self.Wcat = torch.zeros(Xcat.shape[1], self.ld, dtype=f32, device=device)
-            self.Z = torch.zeros(n_pad, self.ld, dtype=f32, device=device)
+            self.Z = torch.zeros(n_pad + 1, self.ld, dtype=f32, device=device)[:n_pad]
             self._sync_wcat()
         else:
             self.Xcat = self.Wcat = None
@@ -358,9 +358,11 @@ class _Engine:
 
     # ------------------------------------------------------------- helpers
     def _padded(self, A64: np.ndarray, rows_pad: int) -> torch.Tensor:
-        out = np.zeros((rows_pad, self.ld), dtype=np.float32)
+        """[rows_pad, ld] fp32 view of a [rows_pad + 1, ld] allocation: the extra last row stays
+        zero for ever - als_row_solve points ratings past the end of a row at it (F_zero_row)."""
+        out = np.zeros((rows_pad + 1, self.ld), dtype=np.float32)
         out[: A64.shape[0], : self.k] = A64
-        return torch.from_numpy(out).to(self.dev)
+        return torch.from_numpy(out).to(self.dev)[:rows_pad]
 
     def _sync_wcat(self):
         off = 0
@@ -408,7 +410,8 @@ class _Engine:
         """scripts/als.py:414-433 on this rank's user shard, then all-gather."""
         md = self.model
         with self._tick("row_solve_user"):
-            self.be.row_solve(k=self.k, ld=self.ld, side=self.csr, F=self.Z, bias_self=self.b_u,
+            self.be.row_solve(k=self.k, ld=self.ld, side=self.csr, F=self.Z, zero_row=self.n_pad,
+                              bias_self=self.b_u,
                               bias_other=self.b_i, mu=self.mu, lam=md.lambda_u, lam_row=None,
                               lam_b=md.lambda_bu, lam_b_row=None, rhs_extra=None, diag_extra=None,
                               X_out=self.U, bias_out=self.b_u, gram_out=None, factor_out=None,
@@ -424,7 +427,7 @@ class _Engine:
         :447,:465): F = U, and the bias update uses V, not Z.
         """
         md = self.model
-        common = dict(k=self.k, ld=self.ld, side=self.csc, F=self.U, bias_self=self.b_i,
+        common = dict(k=self.k, ld=self.ld, side=self.csc, F=self.U, zero_row=self.m_pad, bias_self=self.b_i,
                       bias_other=self.b_u, mu=self.mu, lam=0.0, lam_row=self.lam_v_row,
                       lam_b=md.lambda_bi, lam_b_row=None, rhs_extra=None,
                       gram_out=self.gram if want_gram else None, status=self.status,
@@ -508,12 +511,12 @@ class _Engine:
         # perm-space -> storage order, real columns only
         pos = self.perm[:ld]                       # pos[c] = perm position of storage col c
         pk = pos[:k]
-        Graw = self.gram[sl]                       # [nl, ld, ld] perm space, upper blocks valid
+        Graw = self.gram[sl]                       # [nl, ld, ld] perm space, lower blocks valid
         blk = torch.arange(ld, device=self.dev) // 16
-        up = (blk[:, None] <= blk[None, :])
-        sup = (blk[:, None] < blk[None, :])
-        Gup = torch.where(up, Graw, torch.zeros((), dtype=Graw.dtype, device=self.dev))
-        Gfull = Gup + torch.where(sup, Graw, torch.zeros((), dtype=Graw.dtype, device=self.dev)).transpose(1, 2)
+        lo = (blk[:, None] >= blk[None, :])
+        slo = (blk[:, None] > blk[None, :])
+        Glo = torch.where(lo, Graw, torch.zeros((), dtype=Graw.dtype, device=self.dev))
+        Gfull = Glo + torch.where(slo, Graw, torch.zeros((), dtype=Graw.dtype, device=self.dev)).transpose(1, 2)
         G = Gfull[:, pk][:, :, pk].to(f64)         # [nl, k, k] storage order
         rhs = self.rhs_out[sl][:, pk].to(f64)      # U_i^T r_i with the old b_i
         cs = self.colsum_out[sl][:, pk].to(f64)

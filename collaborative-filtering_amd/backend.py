@@ -46,11 +46,11 @@ class HipBackend:
         return int(self.lib.als_partial_slot_bytes(k))
 
     # -- K1 ------------------------------------------------------------------
-    def row_solve(self, *, k, ld, side, F, bias_self, bias_other, mu, lam, lam_row, lam_b,
+    def row_solve(self, *, k, ld, side, F, zero_row, bias_self, bias_other, mu, lam, lam_row, lam_b,
                   lam_b_row, rhs_extra, diag_extra, X_out, bias_out, gram_out, factor_out,
                   rhs_out, colsum_out, sumr_out, status, tasks, workspace):
         p = _hip.RowSolveParams()
-        p.k, p.ld, p.nrows = k, ld, side.nrows
+        p.k, p.ld, p.nrows, p.F_zero_row = k, ld, side.nrows, int(zero_row)
         p.indptr, p.indices, p.vals = _p(side.indptr), _p(side.indices), _p(side.vals)
         p.F, p.bias_self, p.bias_other, p.mu = _p(F), _p(bias_self), _p(bias_other), _p(mu)
         p.lambda_scalar, p.lambda_row = float(lam), _p(lam_row)

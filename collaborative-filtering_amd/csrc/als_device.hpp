@@ -73,16 +73,17 @@ __device__ __forceinline__ void load_frow(const float* __restrict__ p, float (&f
 template <int KB>
 struct KCfg {
     static constexpr int KP = 16 * KB;
-    // k <= 64: rows 16-byte aligned (uniform ds_read_b128 broadcasts, lane-strided b128
-    // row reads are conflict-free at LD = KP + 4); k > 64: odd stride for column walks
-    static constexpr int LD = (KB <= 4) ? KP + 4 : KP + 1;
-    static constexpr int NACC = KB * (KB + 1) / 2;    // upper 16x16 blocks
+    static constexpr int NACC = KB * (KB + 1) / 2;    // lower 16x16 blocks of the Gram / trailing matrix
     static constexpr int NR = (KP + 63) / 64;         // matrix rows owned per lane
-    static constexpr int LDS_FLOATS = KP * LD + 3 * KP;   // matrix + rhs + colsum + dinv
-    // waves per workgroup chosen so that two workgroups fit a CU's 160 KiB
+    // L in LDS: block column J holds rows [16J, KP) x 16 columns, row stride 16 floats, the four
+    // 4-float groups of a row XOR-swizzled with (row >> 2) & 3 so that b128 row reads by 16
+    // consecutive lanes and b128 operand reads by lanes (c, q) are bank-conflict free.
+    static constexpr int lcol_off(int J) { return 16 * (J * KP - 8 * J * (J - 1)); }
+    __device__ static __forceinline__ int lcol_off_rt(int J) { return 16 * (J * KP - 8 * J * (J - 1)); }
+    static constexpr int LDS_FLOATS = lcol_off(KB);   // 10 KB at k = 64
+    // waves per workgroup / minimum waves per SIMD asked of the register allocator
     static constexpr int WPW = (KB <= 4) ? 4 : (KB <= 6 ? 2 : 1);
-    // minimum waves per SIMD asked of the register allocator (k <= 64: two workgroups per CU)
-    static constexpr int MINW = (KB <= 4) ? 2 : 1;
+    static constexpr int MINW = (KB <= 4) ? 3 : 1;
     static constexpr int SLOT_ITEMS = NACC * 4 + 2 * KB + 1;  // per-lane floats of a partial
     // gather steps (4 ratings each) staged in registers at a time
     static constexpr int GS = (KB <= 4) ? 16 : (KB <= 8 ? 8 : 4);
@@ -117,10 +118,10 @@ __device__ __forceinline__ float solve_regs(const float (&a)[KP], float di, floa
 
 // any KP, L in LDS: Al[j*LD + i] = L[i][j] (i > j), dinv[j] = 1/L[j][j].
 // vec[] (LDS, perm space) holds b on entry and x on exit.
-template <int KB>
+template <int KB, int LD>
 __device__ __forceinline__ void solve_lds(const float* __restrict__ Al, const float* __restrict__ dinv,
                                           float* __restrict__ vec, int lane) {
-    constexpr int KP = KCfg<KB>::KP, LD = KCfg<KB>::LD, NR = KCfg<KB>::NR;
+    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR;
     float rb[NR], di[NR];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {

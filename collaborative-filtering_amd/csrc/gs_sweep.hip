@@ -14,14 +14,21 @@
 namespace {
 
 template <int KB>
-__global__ __launch_bounds__(64 * KCfg<KB>::WPW)
+struct GsCfg {   // waves per workgroup: the k > 64 path keeps a [KP][KP+1] image per wave in LDS
+    static constexpr int WPW = (KB <= 4) ? 4 : (KB <= 6 ? 2 : 1);
+};
+
+template <int KB>
+__global__ __launch_bounds__(64 * GsCfg<KB>::WPW)
 void k_gs_level(const als_gs_sweep_params P) {
     using C = KCfg<KB>;
-    constexpr int KP = C::KP, LD = C::LD, NR = C::NR;
-    __shared__ float lds_all[(KB <= 4) ? 1 : C::WPW * C::LDS_FLOATS];
+    constexpr int KP = C::KP, NR = C::NR;
+    constexpr int LD = KP + 1;                         // k > 64 path: L image [KP][LD] + 3 vectors
+    constexpr int IMG = KP * LD + 3 * KP;
+    __shared__ float lds_all[(KB <= 4) ? 1 : GsCfg<KB>::WPW * IMG];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t tid = (int64_t)blockIdx.x * C::WPW + wave;
+    const int64_t tid = (int64_t)blockIdx.x * GsCfg<KB>::WPW + wave;
     if (tid >= P.nitems) return;
     const int item = P.items[tid];
     const int64_t i64 = item;
@@ -86,7 +93,7 @@ void k_gs_level(const als_gs_sweep_params P) {
         dot = wave_sum(dot);
         if (lane == 0) P.bias[item] = (P.sumr[item] - dot) / (nnz + lb + ALS_EPS);
     } else {
-        float* Al = lds_all + wave * C::LDS_FLOATS;
+        float* Al = lds_all + wave * IMG;
         float* vec = Al + KP * LD;
         float* dinv = vec + 2 * KP;
         for (int p = 0; p < KP; ++p)
@@ -105,7 +112,7 @@ void k_gs_level(const als_gs_sweep_params P) {
             if (i < KP) vec[i] = P.rhs[i64 * KP + i] + P.alpha * g[rr];
         }
         wave_lds_sync();
-        solve_lds<KB>(Al, dinv, vec, lane);
+        solve_lds<KB, LD>(Al, dinv, vec, lane);
         float dot = 0.f;
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) {
@@ -123,10 +130,10 @@ void k_gs_level(const als_gs_sweep_params P) {
 
 template <int KB>
 int launch_gs(const als_gs_sweep_params* p, hipStream_t st) {
-    using C = KCfg<KB>;
+    constexpr int WPW = GsCfg<KB>::WPW;
     if (p->nitems <= 0) return 0;
-    const unsigned grid = (unsigned)((p->nitems + C::WPW - 1) / C::WPW);
-    hipLaunchKernelGGL(k_gs_level<KB>, dim3(grid), dim3(64 * C::WPW), 0, st, *p);
+    const unsigned grid = (unsigned)((p->nitems + WPW - 1) / WPW);
+    hipLaunchKernelGGL(k_gs_level<KB>, dim3(grid), dim3(64 * WPW), 0, st, *p);
     return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
 }
 

@@ -1,15 +1,26 @@
-// K1: per-row normal-equation build (MFMA Gram) + Cholesky solve + bias update.
+// K1: per-row normal-equation build (MFMA Gram) + blocked Cholesky solve + bias update.
 //
 // Replaces the bodies of the user loop (reference scripts/als.py:414-433), the
 // item loop (scripts/als.py:436-466) and cholesky_solve (scripts/helpers.py:5-20).
 //
-// One wavefront owns one task (a row, or a <=4096-rating segment of a long
-// row).  The gathered factor rows never touch LDS on their way to the matrix
+// One wavefront owns one task (a row, or a <=4096-rating segment of a long row).
+//
+// Gram.  The gathered factor rows never touch LDS on their way to the matrix
 // cores: lane (c,q) loads the KB contiguous floats F[idx][KB*c..] of rating
 // 4*s+q, which in "perm space" (als_device.hpp) are position c of every
 // 16-column block, i.e. exactly the A/B operands of v_mfma_f32_16x16x4_f32.
-// The k x k Gram is accumulated in KB(KB+1)/2 upper 16x16 blocks (symmetry),
-// dumped once to LDS and factorised there by the same wave.
+// Only the KB(KB+1)/2 lower 16x16 blocks are accumulated (symmetry).
+//
+// Cholesky.  Right-looking, 16-column panels.  The accumulators that hold the
+// Gram ARE the trailing matrix and stay in registers in MFMA C/D layout.  Per
+// panel J: its block column is dumped to LDS, every lane picks up its row of the
+// panel (16 registers), the panel is factorised on the VALU (pivot and
+// multipliers broadcast with v_readlane), written back, and the rank-16 update
+// of all trailing blocks runs on the matrix cores with operands read straight
+// from the panel image in LDS.  The forward substitution rides along in the
+// panel loop (the right-hand side is one more value per lane), so only the
+// transposed solve is a separate pass.  VALU work is O(k^2 * 16), the O(k^3)
+// part is MFMA.  L lives in LDS as swizzled block columns: 10 KB at k = 64.
 #include "als_device.hpp"
 #include "als_hip.h"
 
@@ -17,7 +28,7 @@ namespace {
 
 template <int KB>
 struct RowAcc {
-    f32x4 acc[KCfg<KB>::NACC];
+    f32x4 acc[KCfg<KB>::NACC];      // lower blocks, index I(I+1)/2 + K  (K <= I)
     float rhs[KB];
     float cs[KB];
     float sumr;
@@ -30,48 +41,44 @@ struct RowAcc {
     }
 };
 
+__host__ __device__ constexpr int blk_idx(int I, int K) { return I * (I + 1) / 2 + K; }
+
 // ---------------------------------------------------------------------------
-// 64 ratings: lane t holds (idx_l, r_l) of rating t; 16 steps of 4 ratings.
+// 64 ratings: lane t holds (off_l, r_l) of rating t; 16 steps of 4 ratings.
+// off_l is the element offset of the rating's factor row (idx * ld); ratings
+// beyond the end of the row point at F's all-zero row with r = 0, so they add
+// nothing and no masking is needed.
 // ---------------------------------------------------------------------------
-template <int KB, bool TAIL>
-__device__ __forceinline__ void process_chunk(RowAcc<KB>& A, int idx_l, float r_l, int nvalid,
-                                              const float* __restrict__ F, int ld, int c, int q) {
+template <int KB, bool FULL>
+__device__ __forceinline__ void process_chunk(RowAcc<KB>& A, int off_l, float r_l, int nvalid,
+                                              const float* __restrict__ Fc, int q) {
     constexpr int GS = KCfg<KB>::GS;
 #pragma unroll
     for (int g0 = 0; g0 < 16; g0 += GS) {
-        if (TAIL && 4 * g0 >= nvalid) break;
+        if (!FULL && 4 * g0 >= nvalid) break;
         float f[GS][KB];
 #pragma unroll
         for (int s = 0; s < GS; ++s) {
-            if (!TAIL || 4 * (g0 + s) < nvalid) {
-                const int src = 4 * (g0 + s) + q;
-                const int idx_t = bperm_i(idx_l, src);       // invalid ratings carry idx 0
-                load_frow<KB>(F + (size_t)idx_t * ld + KB * c, f[s]);
+            if (FULL || 4 * (g0 + s) < nvalid) {
+                const int off_t = bperm_i(off_l, 4 * (g0 + s) + q);
+                load_frow<KB>(Fc + (uint32_t)off_t, f[s]);
             }
         }
 #pragma unroll
         for (int s = 0; s < GS; ++s) {
-            if (!TAIL || 4 * (g0 + s) < nvalid) {
-                const int src = 4 * (g0 + s) + q;
-                const float r_t = bperm_f(r_l, src);          // 0 for invalid ratings
-                if (TAIL) {
-                    const bool ok = src < nvalid;
-#pragma unroll
-                    for (int b = 0; b < KB; ++b) f[s][b] = ok ? f[s][b] : 0.f;
-                }
+            if (FULL || 4 * (g0 + s) < nvalid) {
+                const float r_t = bperm_f(r_l, 4 * (g0 + s) + q);
 #pragma unroll
                 for (int b = 0; b < KB; ++b) {
                     A.rhs[b] = fmaf(f[s][b], r_t, A.rhs[b]);
                     A.cs[b] += f[s][b];
                 }
-                int a = 0;
 #pragma unroll
                 for (int bi = 0; bi < KB; ++bi)
 #pragma unroll
-                    for (int bj = bi; bj < KB; ++bj) {
-                        A.acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[s][bi], f[s][bj], A.acc[a], 0, 0, 0);
-                        ++a;
-                    }
+                    for (int bj = 0; bj <= bi; ++bj)
+                        A.acc[blk_idx(bi, bj)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                            f[s][bi], f[s][bj], A.acc[blk_idx(bi, bj)], 0, 0, 0);
             }
         }
     }
@@ -80,14 +87,15 @@ __device__ __forceinline__ void process_chunk(RowAcc<KB>& A, int idx_l, float r_
 template <int KB>
 __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __restrict__ idxp,
                                                 const float* __restrict__ valp, int len,
-                                                const float* __restrict__ F, int ld,
+                                                const float* __restrict__ F, int ld, int zero_row,
                                                 const float* __restrict__ bias_other, float mu,
                                                 float bself, int lane) {
     const int c = lane & 15, q = lane >> 4;
+    const float* Fc = F + KB * c;
     // software pipeline over 64-rating chunks: indices two chunks ahead,
     // value + opposite-side bias one chunk ahead of the factor-row gathers
-    int idx1 = (lane < len) ? idxp[lane] : 0;
-    int idx2 = (64 + lane < len) ? idxp[64 + lane] : 0;
+    int idx1 = (lane < len) ? idxp[lane] : zero_row;
+    int idx2 = (64 + lane < len) ? idxp[64 + lane] : zero_row;
     float val1 = (lane < len) ? valp[lane] : 0.f;
     float bo1 = (lane < len) ? bias_other[idx1] : 0.f;
     for (int base = 0; base < len; base += 64) {
@@ -95,7 +103,7 @@ __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __
         const float val0 = val1, bo0 = bo1;
         idx1 = idx2;
         const int t2 = base + 128 + lane;
-        idx2 = (t2 < len) ? idxp[t2] : 0;
+        idx2 = (t2 < len) ? idxp[t2] : zero_row;
         const int t1 = base + 64 + lane;
         val1 = (t1 < len) ? valp[t1] : 0.f;
         bo1 = (t1 < len) ? bias_other[idx1] : 0.f;
@@ -104,8 +112,9 @@ __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __
         const float rb = val0 - mu - bo0;
         A.sumr += ok ? rb : 0.f;
         const float r0 = ok ? (rb - bself) : 0.f;
-        if (nvalid == 64) process_chunk<KB, false>(A, idx0, r0, 64, F, ld, c, q);
-        else              process_chunk<KB, true>(A, idx0, r0, nvalid, F, ld, c, q);
+        const int off0 = idx0 * ld;                       // < 2^31 elements (checked by the launcher)
+        if (nvalid == 64) process_chunk<KB, true>(A, off0, r0, 64, Fc, q);
+        else              process_chunk<KB, false>(A, off0, r0, nvalid, Fc, q);
     }
 }
 
@@ -141,132 +150,184 @@ __device__ __forceinline__ void add_partial(RowAcc<KB>& A, const float* __restri
 }
 
 // ---------------------------------------------------------------------------
-// in-LDS / in-register Cholesky.  On exit (both variants):
-//   Al[j*LD + i] = L[i][j] for i > j   (row j of LDS = column j of L)
-//   dinv[j]      = 1 / L[j][j]
-// returns false if a pivot was not positive.
+// blocked Cholesky state of one wave
 // ---------------------------------------------------------------------------
-// KP <= 64: lane i keeps row i of the trailing matrix in registers (static
-// register indices: the column loop is unrolled through templates).  Column j
-// of L is published once to LDS (row j of Al - the layout the callers want
-// anyway) and the rank-1 update reads it back as wave-uniform ds_read_b128
-// broadcasts: 4 multipliers per DS instruction, no SGPR traffic.  Only the
-// pivot of the next step travels by v_readlane.
-template <int KB, int J>
-__device__ __forceinline__ void chol_step(float* __restrict__ Al, int lane, float (&a)[KCfg<KB>::KP],
-                                          float& di, bool& spd) {
-    constexpr int KP = KCfg<KB>::KP, LD = KCfg<KB>::LD;
-    const float d = readlane_f(a[J], J);
-    spd = spd && (d > 0.f);
+template <int KB>
+struct Chol {
+    static constexpr int NR = KCfg<KB>::NR;
+    float di[NR];       // 1 / L[i][i] of the lane's rows i = lane + 64*rr
+    float y[NR];        // forward-solved right-hand side (when SOLVE)
+    float b[NR];        // running right-hand side
+    bool spd;
+};
+
+// one pivot of panel J (column 16J + T): scale the column, ride the forward
+// substitution along, update the remaining columns of the panel
+template <int KB, int J, int T, bool SOLVE>
+__device__ __forceinline__ void panel_pivot(float (&p)[KCfg<KB>::NR][16], Chol<KB>& S, int lane) {
+    constexpr int NR = KCfg<KB>::NR;
+    constexpr int PIV = 16 * J + T, RP = PIV >> 6, LP = PIV & 63;
+    const float d = readlane_f(p[RP][T], LP);
+    S.spd = S.spd && (d > 0.f);
     float inv = __builtin_amdgcn_rsqf(d);
-    inv = inv * fmaf(-0.5f * d * inv, inv, 1.5f);     // one Newton step: <= 1 ulp
-    const float lij = a[J] * inv;                     // L[i][J] for lanes i >= J
-    a[J] = lij;
-    if (lane == J) di = inv;
-    if (lane < KP) Al[J * LD + lane] = lij;           // lanes < J store the unused upper part
-    if constexpr (J + 1 < KP) {
-        // the next pivot column does not wait for the LDS round trip
-        a[J + 1] = fmaf(-lij, readlane_f(lij, J + 1), a[J + 1]);
-        constexpr int G0 = (J + 2) / 4, NG = KP / 4 - G0;
-        if constexpr (NG > 0) {
-            // issue every broadcast read of this step back to back, then consume: left to
-            // itself the compiler keeps ~2 reads in flight and exposes the LDS latency per read
-            f32x4 lc[NG];
+    inv = inv * fmaf(-0.5f * d * inv, inv, 1.5f);          // one Newton step
+    float l[NR];
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
-                lc[g] = *reinterpret_cast<const f32x4*>(Al + J * LD + 4 * (G0 + g));   // uniform address
-            __builtin_amdgcn_sched_barrier(0);
+    for (int rr = 0; rr < NR; ++rr) { l[rr] = p[rr][T] * inv; p[rr][T] = l[rr]; }
+    if (lane == LP) S.di[RP] = inv;
+    if constexpr (SOLVE) {
+        const float yt = readlane_f(S.b[RP], LP) * inv;
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+        for (int rr = 0; rr < NR; ++rr) S.b[rr] = fmaf(-l[rr], yt, S.b[rr]);
+        if (lane == LP) S.y[RP] = yt;
+    }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int cidx = 4 * (G0 + g) + e;
-                    if (cidx > J + 1) a[cidx] = fmaf(-lij, lc[g][e], a[cidx]);
-                }
-            __builtin_amdgcn_sched_barrier(0);
+    for (int t2 = T + 1; t2 < 16; ++t2) {
+        const float s = readlane_f(l[(16 * J + t2) >> 6], (16 * J + t2) & 63);   // L[16J+t2][16J+T]
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) p[rr][t2] = fmaf(-l[rr], s, p[rr][t2]);
+    }
+}
+
+template <int KB, int J, int T, bool SOLVE>
+__device__ __forceinline__ void panel_pivots(float (&p)[KCfg<KB>::NR][16], Chol<KB>& S, int lane) {
+    if constexpr (T < 16) {
+        panel_pivot<KB, J, T, SOLVE>(p, S, lane);
+        panel_pivots<KB, J, T + 1, SOLVE>(p, S, lane);
+    }
+}
+
+// panel J: dump block column -> per-lane rows -> factorise -> write back -> MFMA trailing update
+template <int KB, int J, bool SOLVE>
+__device__ __forceinline__ void chol_panel(RowAcc<KB>& A, Chol<KB>& S, float* __restrict__ Ls, int lane) {
+    using C = KCfg<KB>;
+    constexpr int KP = C::KP, NR = C::NR;
+    constexpr int OFF = C::lcol_off(J);
+    const int c = lane & 15, q = lane >> 4;
+    // 1. accumulators (C/D layout: row 4q + r, col c) of block column J -> LDS panel image
+    {
+        const int swzc = (((c >> 2) ^ q) << 2) + (c & 3);            // (row >> 2) & 3 == q here
+#pragma unroll
+        for (int I = J; I < KB; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Ls[OFF + (16 * (I - J) + 4 * q + r) * 16 + swzc] = A.acc[blk_idx(I, J)][r];
+    }
+    wave_lds_sync();
+    // 2. every lane takes the panel part of its matrix rows
+    float p[NR][16];
+    const int si = (lane >> 2) & 3;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        const int i = lane + 64 * rr;
+        const int rowi = min(max(i, 16 * J), KP - 1) - 16 * J;       // lanes above the panel: dummy row
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(Ls + OFF + rowi * 16 + ((g ^ si) << 2));
+            p[rr][4 * g] = v.x; p[rr][4 * g + 1] = v.y; p[rr][4 * g + 2] = v.z; p[rr][4 * g + 3] = v.w;
+        }
+    }
+    wave_lds_sync();
+    // 3. factorise the panel (rows above a pivot compute garbage in registers nobody reads)
+    panel_pivots<KB, J, 0, SOLVE>(p, S, lane);
+    // 4. L block column J back to LDS (the diagonal block's upper part is never read)
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        const int i = lane + 64 * rr;
+        if (i >= 16 * J && i < KP) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {p[rr][4 * g], p[rr][4 * g + 1], p[rr][4 * g + 2], p[rr][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(Ls + OFF + (i - 16 * J) * 16 + ((g ^ si) << 2)) = v;
+            }
+        }
+    }
+    wave_lds_sync();
+    // 5. trailing update on the matrix cores: acc(I,K) -= L_IJ * L_KJ^T for J < K <= I.
+    //    Lane (c,q) reads L[16I + c][16J + 4q .. 4q+3]: element e is the operand of MFMA step e
+    //    (contraction index 4q + e on both operands).
+    if constexpr (J + 1 < KB) {
+        f32x4 op[KB - J - 1];
+        const int sg = ((q ^ ((c >> 2) & 3)) << 2);
+#pragma unroll
+        for (int I = J + 1; I < KB; ++I)
+            op[I - J - 1] = *reinterpret_cast<const f32x4*>(Ls + OFF + (16 * (I - J) + c) * 16 + sg);
+#pragma unroll
+        for (int K = J + 1; K < KB; ++K) {
+            const f32x4 nb = -op[K - J - 1];
+#pragma unroll
+            for (int I = K; I < KB; ++I)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    A.acc[blk_idx(I, K)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        op[I - J - 1][e], nb[e], A.acc[blk_idx(I, K)], 0, 0, 0);
         }
     }
 }
 
-template <int KB, int J>
-__device__ __forceinline__ void chol_steps(float* __restrict__ Al, int lane, float (&a)[KCfg<KB>::KP],
-                                           float& di, bool& spd) {
-    if constexpr (J < KCfg<KB>::KP) {
-        chol_step<KB, J>(Al, lane, a, di, spd);
-        chol_steps<KB, J + 1>(Al, lane, a, di, spd);
+template <int KB, int J, bool SOLVE>
+__device__ __forceinline__ void chol_panels(RowAcc<KB>& A, Chol<KB>& S, float* __restrict__ Ls, int lane) {
+    if constexpr (J < KB) {
+        chol_panel<KB, J, SOLVE>(A, S, Ls, lane);
+        chol_panels<KB, J + 1, SOLVE>(A, S, Ls, lane);
     }
 }
 
-// On exit a[] is lane i's column of the symmetric completion of L (what
-// solve_regs wants), di = 1/L[i][i], and Al[j*LD + i] = L[i][j].
+// L^T x = y with L in LDS (block columns).  Lane (+64 rr) owns unknown i = lane + 64 rr and
+// reads its column L[p][i], p > i, 16 rows at a time.
 template <int KB>
-__device__ __forceinline__ bool chol_regs(float* __restrict__ Al, int lane,
-                                          float (&a)[KCfg<KB>::KP], float& di) {
-    constexpr int KP = KCfg<KB>::KP, LD = KCfg<KB>::LD;
-    static_assert(LD % 4 == 0, "uniform b128 reads need 16-byte aligned rows");
-    const int i = min(lane, KP - 1);
+__device__ __forceinline__ void backward_solve(const float* __restrict__ Ls, const Chol<KB>& S,
+                                               float (&x)[KCfg<KB>::NR], int lane) {
+    using C = KCfg<KB>;
+    constexpr int KP = C::KP, NR = C::NR;
+    const int c = lane & 15;
+    float rs[NR];
+    int colbase[NR], rowmin[NR];
 #pragma unroll
-    for (int p = 0; p < KP; ++p) a[p] = (p <= lane) ? Al[p * LD + i] : 0.f;   // A[p][i], p <= i (upper)
-    wave_lds_sync();
-    bool spd = true;
-    di = 0.f;
-    chol_steps<KB, 0>(Al, lane, a, di, spd);
-    wave_lds_sync();
-#pragma unroll
-    for (int g4 = 0; g4 < KP / 4; ++g4) {
-        const f32x4 lt = *reinterpret_cast<const f32x4*>(Al + i * LD + 4 * g4);            // L[p][i], p > i
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (4 * g4 + e > lane) a[4 * g4 + e] = lt[e];
+    for (int rr = 0; rr < NR; ++rr) {
+        const int i = min(lane + 64 * rr, KP - 1);
+        const int Ji = i >> 4;
+        rs[rr] = S.y[rr] * S.di[rr];
+        colbase[rr] = C::lcol_off_rt(Ji) - 16 * Ji * 16 + (c & 3);    // + row * 16 + group * 4
+        rowmin[rr] = 16 * Ji;                                         // first row of the lane's block column
     }
-    return spd;
-}
-
-// any KP: everything stays in LDS; lane owns matrix columns lane, lane+64, ...
-template <int KB>
-__device__ __forceinline__ bool chol_lds(float* __restrict__ Al, float* __restrict__ dinv, int lane) {
-    constexpr int KP = KCfg<KB>::KP, LD = KCfg<KB>::LD, NR = KCfg<KB>::NR;
-    bool spd = true;
-    for (int j = 0; j < KP; ++j) {
-        const float d = Al[j * LD + j];
-        spd = spd && (d > 0.f);
-        const float inv = 1.0f / sqrtf(d);
-        float lj[NR];
-        wave_lds_sync();
+#pragma unroll
+    for (int pb = KB - 1; pb >= 0; --pb) {
+        float cf[NR][16];
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) {
             const int i = lane + 64 * rr;
-            lj[rr] = 0.f;
-            if (i > j && i < KP) { lj[rr] = Al[j * LD + i] * inv; Al[j * LD + i] = lj[rr]; }
-        }
-        if (lane == 0) dinv[j] = inv;
-        wave_lds_sync();
-        for (int cidx = j + 1; cidx < KP; ++cidx) {
-            const float lc = Al[j * LD + cidx];           // broadcast L[cidx][j]
 #pragma unroll
-            for (int rr = 0; rr < NR; ++rr) {
-                const int i = lane + 64 * rr;
-                if (i >= cidx && i < KP) Al[cidx * LD + i] = fmaf(-lj[rr], lc, Al[cidx * LD + i]);
+            for (int t = 0; t < 16; ++t) {
+                const int prow = 16 * pb + t;
+                const int grp = ((c >> 2) ^ ((t >> 2) & 3)) << 2;
+                const int rsafe = max(prow, rowmin[rr]);                  // stay inside the block column
+                const float v = Ls[colbase[rr] + rsafe * 16 + grp];
+                cf[rr][t] = (prow > i) ? v * S.di[rr] : 0.f;
             }
         }
-        wave_lds_sync();
+#pragma unroll
+        for (int t = 15; t >= 0; --t) {
+            const int prow = 16 * pb + t;
+            const float xi = readlane_f(rs[prow >> 6], prow & 63);
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) rs[rr] = fmaf(-cf[rr][t], xi, rs[rr]);
+        }
     }
-    return spd;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) x[rr] = rs[rr];
 }
 
 // ---------------------------------------------------------------------------
-// tail: reduce, dump to LDS, regularise, factorise, solve / emit factor
+// tail: reduce, regularise, factorise, solve / emit factor
 // ---------------------------------------------------------------------------
 template <int KB>
 __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_params& P, int row,
-                                           float* __restrict__ lds, int lane) {
+                                           float* __restrict__ Ls, int lane) {
     using C = KCfg<KB>;
-    constexpr int KP = C::KP, LD = C::LD, NR = C::NR;
+    constexpr int KP = C::KP, NR = C::NR;
     const int c = lane & 15, q = lane >> 4;
-    float* Al = lds;
-    float* vrhs = lds + KP * LD;
-    float* vcs = vrhs + KP;
-    float* dinv = vcs + KP;
+    const int64_t r64 = row;
 
     // cross-lane reductions: rhs / colsum over the four q groups, sumr over the wave
 #pragma unroll
@@ -276,122 +337,105 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
     }
     const float sumr = wave_sum(A.sumr);
 
-    // accumulators (C/D layout: col = c, row = 4q + r) -> LDS, upper blocks
-    {
-        int a = 0;
+    // perm position i = lane + 64 rr is block (q + 4 rr), position c: the lane already holds it
+    Chol<KB> S;
+    float csrow[NR];
+    int colrow[NR];
+    S.spd = true;
 #pragma unroll
-        for (int bi = 0; bi < KB; ++bi)
+    for (int rr = 0; rr < NR; ++rr) {
+        float bsel = 0.f, csel = 0.f;
 #pragma unroll
-            for (int bj = bi; bj < KB; ++bj) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Al[(16 * bi + 4 * q + r) * LD + 16 * bj + c] = A.acc[a][r];
-                ++a;
+        for (int e = 0; e < 4; ++e) {
+            constexpr int dummy = 0; (void)dummy;
+            const int b = (4 * rr + e < KB) ? 4 * rr + e : KB - 1;
+            if (4 * rr + e < KB) {
+                bsel = (q == e) ? A.rhs[b] : bsel;
+                csel = (q == e) ? A.cs[b] : csel;
             }
+        }
+        S.b[rr] = bsel; S.di[rr] = 0.f; S.y[rr] = 0.f;
+        csrow[rr] = csel;
+        colrow[rr] = perm_to_col<KB>(min(lane + 64 * rr, KP - 1));
     }
-    if (q == 0) {
-#pragma unroll
-        for (int b = 0; b < KB; ++b) { vrhs[16 * b + c] = A.rhs[b]; vcs[16 * b + c] = A.cs[b]; }
-    }
-    wave_lds_sync();
 
-    const int64_t r64 = row;
-    if (P.gram_out) {
+    if (P.gram_out) {       // F^T F without lambda, perm space, lower 16x16 blocks
         float* G = P.gram_out + r64 * KP * KP;
-        for (int p = 0; p < KP; ++p)
 #pragma unroll
-            for (int rr = 0; rr < NR; ++rr) {
-                const int i = lane + 64 * rr;
-                if (i < KP) G[p * KP + i] = Al[p * LD + i];
-            }
+        for (int I = 0; I < KB; ++I)
+#pragma unroll
+            for (int K = 0; K <= I; ++K)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    G[(16 * I + 4 * q + r) * KP + 16 * K + c] = A.acc[blk_idx(I, K)][r];
     }
-
-    // optional per-row by-products (perm space): rhs, column sums, sum of r + bias_self
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
         const int i = lane + 64 * rr;
         if (i < KP) {
-            if (P.rhs_out) P.rhs_out[r64 * KP + i] = vrhs[i];
-            if (P.colsum_out) P.colsum_out[r64 * KP + i] = vcs[i];
+            if (P.rhs_out) P.rhs_out[r64 * KP + i] = S.b[rr];
+            if (P.colsum_out) P.colsum_out[r64 * KP + i] = csrow[rr];
         }
     }
     if (P.sumr_out && lane == 0) P.sumr_out[row] = sumr;
 
-    // regulariser on the diagonal; padded columns get a unit pivot
+    // regulariser on the diagonal (C/D layout: diagonal where 4q + r == c); padded columns get 1
     const float lam = (P.lambda_row ? P.lambda_row[row] : P.lambda_scalar) + ALS_EPS
                     + (P.diag_extra ? P.diag_extra[row] : 0.f);
 #pragma unroll
-    for (int rr = 0; rr < NR; ++rr) {
-        const int i = lane + 64 * rr;
-        if (i < KP) Al[i * LD + i] += (perm_to_col<KB>(i) < P.k) ? lam : 1.0f;
+    for (int J = 0; J < KB; ++J) {
+        const float dv = (perm_to_col<KB>(16 * J + c) < P.k) ? lam : 1.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A.acc[blk_idx(J, J)][r] += (4 * q + r == c) ? dv : 0.f;
     }
-    wave_lds_sync();
 
-    const float nnz = (float)(P.indptr[row + 1] - P.indptr[row]);
-    const float lb = P.lambda_bias_row ? P.lambda_bias_row[row] : P.lambda_bias_scalar;
-
-    if constexpr (KB <= 4) {
-        // ---- k <= 64: factor and solve in registers --------------------------
-        float a[KP];
-        float di;
-        const bool spd = chol_regs<KB>(Al, lane, a, di);
-        if (!spd && lane == 0) atomicMax(P.status, row + 1);
-        const int i = min(lane, KP - 1);
-        if (P.factor_out) {
-            float* M = P.factor_out + r64 * KP * KP;
-#pragma unroll
-            for (int p = 0; p < KP; ++p)
-                if (lane < KP) M[p * KP + lane] = (p == lane) ? di : a[p];
-            return;
-        }
-        const int col = perm_to_col<KB>(i);
-        float rb = vrhs[i];
-        if (P.rhs_extra) rb += P.rhs_extra[r64 * P.ld + col];
-        const float x = solve_regs<KP>(a, di, rb, lane);
-        float dot = 0.f;
-        if (lane < KP) {
-            P.X_out[r64 * P.ld + col] = x;
-            dot = vcs[lane] * x;
-        }
-        dot = wave_sum(dot);
-        if (lane == 0) P.bias_out[row] = (sumr - dot) / (nnz + lb + ALS_EPS);
-    } else {
-        // ---- k > 64: everything through LDS ----------------------------------
-        const bool spd = chol_lds<KB>(Al, dinv, lane);
-        if (!spd && lane == 0) atomicMax(P.status, row + 1);
-        if (P.factor_out) {
-            float* M = P.factor_out + r64 * KP * KP;
-            for (int p = 0; p < KP; ++p)
-#pragma unroll
-                for (int rr = 0; rr < NR; ++rr) {
-                    const int i = lane + 64 * rr;
-                    if (i < KP) {
-                        const int lo = min(p, i), hi = max(p, i);
-                        M[p * KP + i] = (p == i) ? dinv[i] : Al[lo * LD + hi];
-                    }
-                }
-            return;
-        }
-        if (P.rhs_extra) {
-#pragma unroll
-            for (int rr = 0; rr < NR; ++rr) {
-                const int i = lane + 64 * rr;
-                if (i < KP) vrhs[i] += P.rhs_extra[r64 * P.ld + perm_to_col<KB>(i)];
-            }
-            wave_lds_sync();
-        }
-        solve_lds<KB>(Al, dinv, vrhs, lane);
-        float dot = 0.f;
+    if (P.factor_out) {
+        chol_panels<KB, 0, false>(A, S, Ls, lane);
+        if (!S.spd && lane == 0) atomicMax(P.status, row + 1);
+        // symmetric completion of L with 1/L_ii on the diagonal, perm space:
+        // M[p][i] = L[i][p] (p < i), L[p][i] (p > i)
+        float* M = P.factor_out + r64 * KP * KP;
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) {
             const int i = lane + 64 * rr;
-            if (i < KP) {
-                const float x = vrhs[i];
-                P.X_out[r64 * P.ld + perm_to_col<KB>(i)] = x;
-                dot = fmaf(vcs[i], x, dot);
+            const int ic = min(i, KP - 1);
+            const int colb = C::lcol_off_rt(ic >> 4) - 16 * (ic >> 4) * 16 + (c & 3);
+            for (int p = 0; p < KP; ++p) {
+                const int Jp = p >> 4;
+                const int rowv = max(ic, 16 * Jp);                                   // row i inside block column Jp
+                const float lrow = Ls[C::lcol_off_rt(Jp) + (rowv - 16 * Jp) * 16 +
+                                      ((((p >> 2) & 3) ^ ((rowv >> 2) & 3)) << 2) + (p & 3)];
+                const int rsafe = max(p, ic & ~15);
+                const float lcolv = Ls[colb + rsafe * 16 + (((c >> 2) ^ ((rsafe >> 2) & 3)) << 2)];
+                if (i < KP) M[p * KP + i] = (p == i) ? S.di[rr] : (p < i ? lrow : lcolv);
             }
         }
-        dot = wave_sum(dot);
-        if (lane == 0) P.bias_out[row] = (sumr - dot) / (nnz + lb + ALS_EPS);
+        return;
+    }
+
+    if (P.rhs_extra) {
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr)
+            if (lane + 64 * rr < KP) S.b[rr] += P.rhs_extra[r64 * P.ld + colrow[rr]];
+    }
+    chol_panels<KB, 0, true>(A, S, Ls, lane);
+    if (!S.spd && lane == 0) atomicMax(P.status, row + 1);
+    float x[NR];
+    backward_solve<KB>(Ls, S, x, lane);
+
+    float dot = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        if (lane + 64 * rr < KP) {
+            P.X_out[r64 * P.ld + colrow[rr]] = x[rr];
+            dot = fmaf(csrow[rr], x[rr], dot);
+        }
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) {
+        const float nnz = (float)(P.indptr[row + 1] - P.indptr[row]);
+        const float lb = P.lambda_bias_row ? P.lambda_bias_row[row] : P.lambda_bias_scalar;
+        P.bias_out[row] = (sumr - dot) / (nnz + lb + ALS_EPS);
     }
 }
 
@@ -399,7 +443,7 @@ template <int KB>
 __global__ __launch_bounds__(64 * KCfg<KB>::WPW, KCfg<KB>::MINW)
 void k_row_tasks(const als_row_solve_params P) {
     using C = KCfg<KB>;
-    __shared__ float lds_all[C::WPW * C::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds_all[C::WPW * C::LDS_FLOATS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t tid = (int64_t)blockIdx.x * C::WPW + wave;
@@ -414,7 +458,8 @@ void k_row_tasks(const als_row_solve_params P) {
 
     RowAcc<KB> A;
     A.zero();
-    gram_accumulate<KB>(A, P.indices + beg, P.vals + beg, len, P.F, P.ld, P.bias_other, mu, bself, lane);
+    gram_accumulate<KB>(A, P.indices + beg, P.vals + beg, len, P.F, P.ld, P.F_zero_row, P.bias_other,
+                        mu, bself, lane);
     if (t.slot >= 0) {
         store_partial<KB>(A, (float*)P.workspace + (size_t)t.slot * C::SLOT_ITEMS * 64, lane);
         return;
@@ -426,7 +471,7 @@ template <int KB>
 __global__ __launch_bounds__(64 * KCfg<KB>::WPW, KCfg<KB>::MINW)
 void k_row_long(const als_row_solve_params P) {
     using C = KCfg<KB>;
-    __shared__ float lds_all[C::WPW * C::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds_all[C::WPW * C::LDS_FLOATS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t tid = (int64_t)blockIdx.x * C::WPW + wave;
@@ -475,7 +520,8 @@ extern "C" int als_row_solve(const als_row_solve_params* p, void* stream) {
     const int ld = als_padded_k(p->k);
     if (ld < 0) return ALS_E_BADK;
     if (p->ld != ld || !p->indptr || !p->indices || !p->vals || !p->F || !p->bias_self ||
-        !p->bias_other || !p->mu || !p->status || p->ntasks < 0 || p->nlong < 0)
+        !p->bias_other || !p->mu || !p->status || p->ntasks < 0 || p->nlong < 0 || p->F_zero_row < 0 ||
+        (int64_t)p->F_zero_row * ld >= ((int64_t)1 << 31))
         return ALS_E_BADARG;
     if (p->ntasks > 0 && !p->tasks) return ALS_E_BADARG;
     if (p->nlong > 0 && (!p->long_rows || !p->workspace)) return ALS_E_BADARG;

@@ -85,8 +85,9 @@ int64_t als_partial_slot_bytes(int k);
  * previous X/bias, as in the reference).
  *
  * Optional outputs
- *   gram_out   [nrows][ld][ld]  F^T F (no lambda), perm space, upper 16x16
- *                               blocks valid (lower blocks unspecified).
+ *   gram_out   [nrows][ld][ld]  F^T F (no lambda), perm space, lower 16x16
+ *                               blocks (block row >= block col) written; the
+ *                               upper blocks are left untouched.
  *   rhs_out    [nrows][ld]    F^T r (perm space, without rhs_extra),
  *   colsum_out [nrows][ld]    sum_t F_t (perm space),
  *   sumr_out   [nrows]        sum_t(vals[t] - mu - bias_other[indices[t]])
@@ -104,6 +105,10 @@ typedef struct als_row_solve_params {
     int32_t k;
     int32_t ld;                 /* = als_padded_k(k); ld of F, X_out, rhs_extra */
     int64_t nrows;              /* rows in this orientation (bounds checks only) */
+    int32_t F_zero_row;         /* index of an all-zero row of F (ratings past the end of a
+                                   row are pointed at it instead of being masked); F_zero_row*ld
+                                   and every indices[t]*ld must be < 2^31 */
+    int32_t reserved0;
     const int64_t* indptr;
     const int32_t* indices;
     const float*   vals;

@@ -2,7 +2,7 @@
 
 Implements the backend interface of the engine (als.py) with numpy on CPU
 tensors, using the same per-row formulas as the oracle, and the same output
-conventions as the C ABI (perm space, upper-block Gram, factor completion).
+conventions as the C ABI (perm space, lower-block Gram, factor completion).
 It exists so that the host-side logic - sharding, all-gathers, the Gauss-Seidel
 level schedule, the W-step algebra, early stopping - can be tested without a
 GPU (world_size-2 gloo tests).  It is never imported by the product package.
@@ -37,10 +37,11 @@ class NumpyBackend:
         t = _np(tasks.tasks)
         return np.unique(t[:, 0]) if t.size else np.zeros(0, np.int64)
 
-    def row_solve(self, *, k, ld, side, F, bias_self, bias_other, mu, lam, lam_row, lam_b, lam_b_row,
+    def row_solve(self, *, k, ld, side, F, zero_row, bias_self, bias_other, mu, lam, lam_row, lam_b, lam_b_row,
                   rhs_extra, diag_extra, X_out, bias_out, gram_out, factor_out, rhs_out, colsum_out,
                   sumr_out, status, tasks, workspace):
         ptr, idx, vals = _np(side.indptr), _np(side.indices), _np(side.vals)
+        # zero_row indexes the extra all-zero row behind the [rows_pad, ld] view; unused here
         Fn = _np(F)[:, :k].astype(self.dtype)
         bs, bo = _np(bias_self), _np(bias_other)
         pos = layout.perm_of_col(k)
@@ -61,7 +62,7 @@ class NumpyBackend:
             if gram_out is not None:
                 Gp = np.zeros((ld, ld), dtype=np.float32)
                 Gp[np.ix_(pos[:k], pos[:k])] = G
-                Gp[blk[:, None] > blk[None, :]] = np.nan      # lower blocks: unspecified
+                Gp[blk[:, None] < blk[None, :]] = np.nan      # upper blocks: not written by the kernel
                 gram_out[r] = torch.from_numpy(Gp)
             if rhs_out is not None:
                 t = np.zeros(ld, dtype=np.float32); t[pos[:k]] = b; rhs_out[r] = torch.from_numpy(t)

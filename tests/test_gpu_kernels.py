@@ -28,9 +28,9 @@ def _random_side(layout, nrows, ncols, lens, seed):
     return layout.SparseSide(nrows, ncols, indptr, idx, vals)
 
 
-def _pad(A, ld):
-    out = np.zeros((A.shape[0], ld), dtype=np.float32)
-    out[:, : A.shape[1]] = A
+def _pad(A, ld, extra_rows=0):
+    out = np.zeros((A.shape[0] + extra_rows, ld), dtype=np.float32)
+    out[: A.shape[0], : A.shape[1]] = A
     return out
 
 
@@ -59,7 +59,7 @@ def test_row_solve_against_numpy(k):
     gram = torch.zeros(nrows, ld, ld, dtype=f32, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     ws = torch.empty(t.nslots * be.slot_bytes(k) // 4, dtype=f32, device=dev)
-    be.row_solve(k=k, ld=ld, side=sd, F=torch.from_numpy(_pad(F, ld)).to(dev),
+    be.row_solve(k=k, ld=ld, side=sd, F=torch.from_numpy(_pad(F, ld, 1)).to(dev), zero_row=ncols,
                  bias_self=torch.from_numpy(b_self.astype(np.float32)).to(dev),
                  bias_other=torch.from_numpy(b_other.astype(np.float32)).to(dev),
                  mu=torch.tensor([mu], dtype=torch.float64, device=dev), lam=0.0,
@@ -93,11 +93,10 @@ def test_row_solve_against_numpy(k):
         bref = np.sum(vals - Fr @ x - mu - b_other.astype(np.float32)[idx]) / ((hi - lo) + lam_b + 1e-10)
         assert abs(bias[r] - bref) <= 2e-4 * max(1.0, abs(bref)), (r, bias[r], bref)
         Gr = G[r][np.ix_(pos, pos)]
-        Gu = np.triu(Fr.T @ Fr)
         blk = pos // 16
-        upper_block = blk[:, None] <= blk[None, :]            # documented valid region
+        lower_block = blk[:, None] >= blk[None, :]            # documented valid region
         ref = Fr.T @ Fr
-        np.testing.assert_allclose(Gr[upper_block], ref[upper_block], rtol=1e-4,
+        np.testing.assert_allclose(Gr[lower_block], ref[lower_block], rtol=1e-4,
                                    atol=1e-5 * max(np.max(np.abs(ref)), 1e-6))
 
 
@@ -140,7 +139,7 @@ def test_factor_mode_and_gs_level(k):
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     ws = torch.empty(max(t.nslots, 1) * be.slot_bytes(k) // 4, dtype=f32, device=dev)
     mu_t = torch.tensor([mu], dtype=torch.float64, device=dev)
-    be.row_solve(k=k, ld=ld, side=sd, F=tt(_pad(F, ld)), bias_self=tt(b_self), bias_other=tt(b_other),
+    be.row_solve(k=k, ld=ld, side=sd, F=tt(_pad(F, ld, 1)), zero_row=ncols, bias_self=tt(b_self), bias_other=tt(b_other),
                  mu=mu_t, lam=0.0, lam_row=tt(lam_row), lam_b=lam_b, lam_b_row=None, rhs_extra=None,
                  diag_extra=tt(alpha * D), X_out=None, bias_out=None, gram_out=None, factor_out=factor,
                  rhs_out=rhs, colsum_out=cs, sumr_out=sumr, status=status, tasks=td, workspace=ws)
