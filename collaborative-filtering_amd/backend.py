@@ -32,6 +32,7 @@ class HipBackend:
         self._sumsq_partials = torch.empty(self.lib.als_sumsq_partials(), dtype=torch.float64,
                                            device=device)
         self._stats_partials: Optional[torch.Tensor] = None
+        self.ablate = int(__import__('os').environ.get('ALS_ABLATE', '0'))   # diagnostics only
 
     # -- helpers -------------------------------------------------------------
     def _stream(self):
@@ -51,6 +52,7 @@ class HipBackend:
                   rhs_out, colsum_out, sumr_out, status, tasks, workspace):
         p = _hip.RowSolveParams()
         p.k, p.ld, p.nrows, p.F_zero_row = k, ld, side.nrows, int(zero_row)
+        p.reserved0 = self.ablate          # 0 in production; profiling builds of bench.py set it
         p.indptr, p.indices, p.vals = _p(side.indptr), _p(side.indices), _p(side.vals)
         p.F, p.bias_self, p.bias_other, p.mu = _p(F), _p(bias_self), _p(bias_other), _p(mu)
         p.lambda_scalar, p.lambda_row = float(lam), _p(lam_row)

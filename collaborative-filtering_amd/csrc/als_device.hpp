@@ -86,7 +86,7 @@ struct KCfg {
     static constexpr int MINW = (KB <= 4) ? 3 : 1;
     static constexpr int SLOT_ITEMS = NACC * 4 + 2 * KB + 1;  // per-lane floats of a partial
     // gather steps (4 ratings each) staged in registers at a time
-    static constexpr int GS = (KB <= 4) ? 16 : (KB <= 8 ? 8 : 4);
+    static constexpr int GS = (KB <= 8) ? 8 : 4;
 };
 
 // ---------------------------------------------------------------------------

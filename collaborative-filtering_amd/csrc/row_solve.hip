@@ -57,20 +57,23 @@ __device__ __forceinline__ void process_chunk(RowAcc<KB>& A, int off_l, float r_
     for (int g0 = 0; g0 < 16; g0 += GS) {
         if (!FULL && 4 * g0 >= nvalid) break;
         float f[GS][KB];
+        int off_t[GS];
+        float r_t[GS];
+        // all cross-lane moves of the group first (one LDS-crossbar round trip), then the loads
 #pragma unroll
         for (int s = 0; s < GS; ++s) {
-            if (FULL || 4 * (g0 + s) < nvalid) {
-                const int off_t = bperm_i(off_l, 4 * (g0 + s) + q);
-                load_frow<KB>(Fc + (uint32_t)off_t, f[s]);
-            }
+            off_t[s] = bperm_i(off_l, 4 * (g0 + s) + q);
+            r_t[s] = bperm_f(r_l, 4 * (g0 + s) + q);
         }
 #pragma unroll
+        for (int s = 0; s < GS; ++s)
+            if (FULL || 4 * (g0 + s) < nvalid) load_frow<KB>(Fc + (uint32_t)off_t[s], f[s]);
+#pragma unroll
         for (int s = 0; s < GS; ++s) {
             if (FULL || 4 * (g0 + s) < nvalid) {
-                const float r_t = bperm_f(r_l, 4 * (g0 + s) + q);
 #pragma unroll
                 for (int b = 0; b < KB; ++b) {
-                    A.rhs[b] = fmaf(f[s][b], r_t, A.rhs[b]);
+                    A.rhs[b] = fmaf(f[s][b], r_t[s], A.rhs[b]);
                     A.cs[b] += f[s][b];
                 }
 #pragma unroll
@@ -169,23 +172,27 @@ __device__ __forceinline__ void panel_pivot(float (&p)[KCfg<KB>::NR][16], Chol<K
     constexpr int PIV = 16 * J + T, RP = PIV >> 6, LP = PIV & 63;
     const float d = readlane_f(p[RP][T], LP);
     S.spd = S.spd && (d > 0.f);
-    float inv = __builtin_amdgcn_rsqf(d);
-    inv = inv * fmaf(-0.5f * d * inv, inv, 1.5f);          // one Newton step
+    const float inv = __builtin_amdgcn_rsqf(d);            // v_rsq_f32: 1 ulp, ample for the fp32 tolerance
     float l[NR];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) { l[rr] = p[rr][T] * inv; p[rr][T] = l[rr]; }
     if (lane == LP) S.di[RP] = inv;
+    // multipliers L[16J+t2][16J+T] first (wave-uniform, in SGPRs), then the FMAs: keeps the
+    // v_readlane -> SGPR -> VALU hazard slots filled with independent work
+    float s[16 - T > 1 ? 15 - T : 1];
+#pragma unroll
+    for (int t2 = T + 1; t2 < 16; ++t2)
+        s[t2 - T - 1] = readlane_f(l[(16 * J + t2) >> 6], (16 * J + t2) & 63);
+    float yt = 0.f;
+    if constexpr (SOLVE) yt = readlane_f(S.b[RP], LP) * inv;
+#pragma unroll
+    for (int t2 = T + 1; t2 < 16; ++t2)
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) p[rr][t2] = fmaf(-l[rr], s[t2 - T - 1], p[rr][t2]);
     if constexpr (SOLVE) {
-        const float yt = readlane_f(S.b[RP], LP) * inv;
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) S.b[rr] = fmaf(-l[rr], yt, S.b[rr]);
         if (lane == LP) S.y[RP] = yt;
-    }
-#pragma unroll
-    for (int t2 = T + 1; t2 < 16; ++t2) {
-        const float s = readlane_f(l[(16 * J + t2) >> 6], (16 * J + t2) & 63);   // L[16J+t2][16J+T]
-#pragma unroll
-        for (int rr = 0; rr < NR; ++rr) p[rr][t2] = fmaf(-l[rr], s, p[rr][t2]);
     }
 }
 
@@ -418,10 +425,14 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
         for (int rr = 0; rr < NR; ++rr)
             if (lane + 64 * rr < KP) S.b[rr] += P.rhs_extra[r64 * P.ld + colrow[rr]];
     }
-    chol_panels<KB, 0, true>(A, S, Ls, lane);
+    if (!(P.reserved0 & 2)) chol_panels<KB, 0, true>(A, S, Ls, lane);
     if (!S.spd && lane == 0) atomicMax(P.status, row + 1);
     float x[NR];
-    backward_solve<KB>(Ls, S, x, lane);
+    if (!(P.reserved0 & 4)) backward_solve<KB>(Ls, S, x, lane);
+    else {
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) x[rr] = S.y[rr];
+    }
 
     float dot = 0.f;
 #pragma unroll
@@ -446,25 +457,31 @@ void k_row_tasks(const als_row_solve_params P) {
     __shared__ __attribute__((aligned(16))) float lds_all[C::WPW * C::LDS_FLOATS];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t tid = (int64_t)blockIdx.x * C::WPW + wave;
+    // everything that describes the task is wave-uniform: keep it in SGPRs (scalar loads,
+    // scalar branches in the chunk loop)
+    const int wave_u = wave;
+    const int64_t tid = (int64_t)blockIdx.x * C::WPW + wave_u;
     if (tid >= P.ntasks) return;
     const als_task t = P.tasks[tid];
     const int row = t.row;
+    const int seg = t.seg;
+    const int slot = t.slot;
     const int64_t rbeg = P.indptr[row], rend = P.indptr[row + 1];
-    const int64_t beg = rbeg + (int64_t)t.seg * ALS_SPLIT_CHUNK;
+    const int64_t beg = rbeg + (int64_t)seg * ALS_SPLIT_CHUNK;
     const int len = (int)min((int64_t)ALS_SPLIT_CHUNK, rend - beg);
     const float mu = (float)(*P.mu);
     const float bself = P.bias_self[row];
 
     RowAcc<KB> A;
     A.zero();
-    gram_accumulate<KB>(A, P.indices + beg, P.vals + beg, len, P.F, P.ld, P.F_zero_row, P.bias_other,
-                        mu, bself, lane);
-    if (t.slot >= 0) {
-        store_partial<KB>(A, (float*)P.workspace + (size_t)t.slot * C::SLOT_ITEMS * 64, lane);
+    if (!(P.reserved0 & 1))        // reserved0: ablation flags for profiling builds, 0 in production
+        gram_accumulate<KB>(A, P.indices + beg, P.vals + beg, len, P.F, P.ld, P.F_zero_row, P.bias_other,
+                            mu, bself, lane);
+    if (slot >= 0) {
+        store_partial<KB>(A, (float*)P.workspace + (size_t)slot * C::SLOT_ITEMS * 64, lane);
         return;
     }
-    finish_row<KB>(A, P, row, lds_all + wave * C::LDS_FLOATS, lane);
+    finish_row<KB>(A, P, row, lds_all + wave_u * C::LDS_FLOATS, lane);
 }
 
 template <int KB>
