@@ -142,7 +142,7 @@ def cpu_baseline(eng, budget_s=20.0):
     b_i = eng.b_i[: eng.n].double().cpu().numpy()
     mu = float(eng.mu.item())
     # ---- users: rows [0, su)
-    su = int(np.searchsorted(uptr, 6_000_000))
+    su = int(np.searchsorted(uptr, 12_000_000))
     su = max(1, min(su, eng.m))
     nu = int(uptr[su])
     rt = Ratings(su, eng.n, None, eng.csr.indices[:nu].cpu().numpy().astype(np.int64),
@@ -160,7 +160,7 @@ def cpu_baseline(eng, budget_s=20.0):
             break
     tu = time.perf_counter() - t0
     # ---- items: columns [0, si) with users remapped to a compact range
-    si = int(np.searchsorted(iptr, 6_000_000))
+    si = int(np.searchsorted(iptr, 12_000_000))
     si = max(1, min(si, eng.n))
     ni = int(iptr[si])
     users = eng.csc.indices[:ni].cpu().numpy().astype(np.int64)
@@ -303,6 +303,16 @@ def main():
                 "hbm_view": {"achieved_GBps": by / t_rs / 1e9, "peak_GBps": 8000.0,
                              "frac": by / t_rs / 1e9 / 8000.0, "algorithmic_bytes_per_launch": by / n_launch},
                 "traffic": None}
+        # HBM bytes per launch from the committed PMC pass (profiles/collect_pmc.sh; FETCH_SIZE doubled as
+        # MI355X_MICROARCH.md prescribes for gfx950) - only meaningful for the workload it was taken on
+        import glob
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_row_tasks.json")))
+        if pm and args.size == "cfg4" and world == 1:
+            roof["traffic"] = json.load(open(pm[-1]))["traffic_bytes_per_launch_mean"]
+            roof["traffic_source"] = os.path.relpath(pm[-1], ROOT)
+        # the kernel exploits the symmetry of the Gram (10 of 16 blocks): matrix-core work actually issued
+        fl_exec = (2 * k * k * 10 / 16 + 4 * k) * (nn_u + nn_i)
+        roof["executed_gram_frac_of_peak"] = fl_exec / t_rs / 1e12 / 157.3
         out = {
             "metric": "ratings/sec per ALS iteration at k=64", "value": nnz / (elapsed / args.steps),
             "unit": "ratings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -1,0 +1,111 @@
+"""T5 (CPU, gloo, world_size 2): the N>1 path of the engine - user/item sharding,
+in-place all-gathers of the factor blocks, all-reduce of the statistics and of the
+W-step normal equations, block / exact Gauss-Seidel modes.  The per-row arithmetic is
+supplied by the test-only numpy stand-in (tests/cpu_backend.py); what is under test is
+the host logic that the 2/4/8-GPU runs execute unchanged with the HIP backend."""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, name, gs_mode, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.common import Golden
+        from tests.cpu_backend import NumpyBackend
+        from tests.test_gpu_parity import _model_for
+        g = Golden(name)
+        r, c, v = g.train
+        model = _model_for(g, device="cpu", backend=NumpyBackend(), gs_mode=gs_mode)
+        model.fit_coo(r, c, v, (g.m, g.n), features=g.features or None, tol=g.cfg["tol"],
+                      min_iters=g.cfg["min_iters"], verbose=0)
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), U=model.U, V=model.V, b_u=model.b_u,
+                 b_i=model.b_i, mu=model.mu, rmse=np.asarray(model.history["train_rmse"]),
+                 **{"W_" + f: model.W[f] for f in g.cfg["feats"]})
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(name, gs_mode=None, world=2):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), name, gs_mode, d), nprocs=world, join=True)
+        return [np.load(os.path.join(d, f"rank{r}.npz")) for r in range(world)]
+
+
+def _single(name):
+    from tests.common import Golden
+    from tests.cpu_backend import NumpyBackend
+    from tests.test_gpu_parity import _model_for
+    g = Golden(name)
+    r, c, v = g.train
+    model = _model_for(g, device="cpu", backend=NumpyBackend())
+    model.fit_coo(r, c, v, (g.m, g.n), features=g.features or None, tol=g.cfg["tol"],
+                  min_iters=g.cfg["min_iters"], verbose=0)
+    return g, model
+
+
+@pytest.mark.parametrize("name", ["g2_bias_pop", "g3_empty", "g4_feat_uw2"])
+def test_two_ranks_equal_one_rank(name):
+    """Sharding must not change per-row arithmetic: factors identical on both ranks and equal to
+    the single-process run (bitwise without features; the W-step all-reduce changes the summation
+    order of the (d k)^2 normal equations, hence a tight tolerance there)."""
+    g, ref = _single(name)
+    outs = _run(name)
+    for key in ("U", "V", "b_u", "b_i", "rmse"):
+        np.testing.assert_array_equal(outs[0][key], outs[1][key], err_msg=f"ranks disagree on {key}")
+    tol = dict(rtol=0, atol=0) if not g.cfg["feats"] else dict(rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(outs[0]["U"], ref.U, **tol)
+    np.testing.assert_allclose(outs[0]["V"], ref.V, **tol)
+    np.testing.assert_allclose(outs[0]["rmse"], ref.history["train_rmse"], rtol=1e-9 if g.cfg["feats"] else 1e-12)
+    # and the sharded run still reproduces the reference fixture
+    np.testing.assert_allclose(outs[0]["rmse"], g.d["hist_train_rmse"], atol=2e-6)
+
+
+def test_exact_gauss_seidel_across_ranks():
+    """gs_mode='exact': per-level exchange of fresh V rows reproduces the sequential sweep."""
+    g, ref = _single("g5_graph_a0.5")
+    outs = _run("g5_graph_a0.5", gs_mode="exact")
+    np.testing.assert_array_equal(outs[0]["V"], outs[1]["V"])
+    np.testing.assert_allclose(outs[0]["V"], ref.V, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(outs[0]["rmse"], g.d["hist_train_rmse"], atol=2e-6)
+
+
+def test_block_gauss_seidel_is_close_and_consistent():
+    """gs_mode='block' (default for N>1): Gauss-Seidel inside an item shard, previous-iteration
+    values across shards.  Not the reference's order - the deviation is bounded here and stated
+    in DESIGN.md; both ranks must still agree bitwise."""
+    g, ref = _single("g5_graph_a0.5")
+    outs = _run("g5_graph_a0.5", gs_mode="block")
+    np.testing.assert_array_equal(outs[0]["V"], outs[1]["V"])
+    assert np.max(np.abs(outs[0]["rmse"] - np.asarray(ref.history["train_rmse"]))) < 5e-3
+    assert np.max(np.abs(outs[0]["rmse"] - np.asarray(ref.history["train_rmse"]))) > 0   # it is a different sweep
+
+
+def test_three_ranks_uneven_shards():
+    """world_size 3 on 300 x 200: shard sizes do not divide evenly (padding rows of the last rank)."""
+    g, ref = _single("g2_bias_pop")
+    outs = _run("g2_bias_pop", world=3)
+    for r in (1, 2):
+        np.testing.assert_array_equal(outs[0]["U"], outs[r]["U"])
+    np.testing.assert_array_equal(outs[0]["U"], ref.U)
+    np.testing.assert_array_equal(outs[0]["V"], ref.V)
