@@ -204,15 +204,22 @@ def main():
     ap.add_argument("--gs-mode", default=None, choices=[None, "exact", "block"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="debug only; not a valid headline run")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N>1 code path with several ranks on ONE GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ngpu = torch.cuda.device_count()
+    local = local % max(ngpu, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 

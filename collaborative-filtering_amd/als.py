@@ -453,6 +453,14 @@ class _Engine:
         md = self.model
         off = self.sched.offsets
         exact_multi = self.world > 1 and self.gs_mode == "exact"
+        kw = dict(k=self.k, ld=self.ld, S_ptr=self.S_ptr, S_idx=self.S_idx, S_val=self.S_val,
+                  alpha=md.alpha, factor=self.factor, rhs=self.rhs_out, colsum=self.colsum_out,
+                  sumr=self.sumr, indptr=self.csc.indptr, lam_b=md.lambda_bi, lam_b_row=None,
+                  V=self.V, bias=self.b_i)
+        if not exact_multi and hasattr(self.be, "gs_levels"):
+            # no collective between levels: the whole sweep is one C call (one launch per level)
+            self.be.gs_levels(offsets=np.ascontiguousarray(off, dtype=np.int64), items=self.sched_items, **kw)
+            return
         for lv in range(len(off) - 1):
             items = self.sched_items[off[lv]:off[lv + 1]]
             if exact_multi:
@@ -463,10 +471,7 @@ class _Engine:
             else:
                 mine = items
             if mine.numel():
-                self.be.gs_level(k=self.k, ld=self.ld, items=mine, S_ptr=self.S_ptr, S_idx=self.S_idx,
-                                 S_val=self.S_val, alpha=md.alpha, factor=self.factor, rhs=self.rhs_out,
-                                 colsum=self.colsum_out, sumr=self.sumr, indptr=self.csc.indptr,
-                                 lam_b=md.lambda_bi, lam_b_row=None, V=self.V, bias=self.b_i)
+                self.be.gs_level(items=mine, **kw)
             if exact_multi:
                 self._exchange_level(items, it_np)
 

@@ -77,6 +77,20 @@ class HipBackend:
         p.V, p.bias = _p(V), _p(bias)
         self._check(self.lib.als_gs_sweep(C.byref(p), self._stream()), "als_gs_sweep")
 
+    def gs_levels(self, *, offsets, **kw):
+        """All levels of the sweep with one C call (offsets: host int64 numpy array, nlevels+1)."""
+        items = kw.pop("items")
+        p = _hip.GsSweepParams()
+        p.k, p.ld = kw["k"], kw["ld"]
+        p.items, p.nitems = _p(items), 0
+        p.S_ptr, p.S_idx, p.S_val, p.alpha = _p(kw["S_ptr"]), _p(kw["S_idx"]), _p(kw["S_val"]), float(kw["alpha"])
+        p.factor, p.rhs, p.colsum, p.sumr = _p(kw["factor"]), _p(kw["rhs"]), _p(kw["colsum"]), _p(kw["sumr"])
+        p.indptr, p.lambda_bias_scalar, p.lambda_bias_row = _p(kw["indptr"]), float(kw["lam_b"]), _p(kw["lam_b_row"])
+        p.V, p.bias = _p(kw["V"]), _p(kw["bias"])
+        off = offsets.ctypes.data_as(C.c_void_p)
+        self._check(self.lib.als_gs_sweep_levels(C.byref(p), off, len(offsets) - 1, self._stream()),
+                    "als_gs_sweep_levels")
+
     # -- K6 ------------------------------------------------------------------
     def residual_stats(self, *, k, ld, side, U, Z, b_u, b_i, mu, tasks, out):
         if tasks.ntasks == 0:

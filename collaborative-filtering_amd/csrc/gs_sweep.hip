@@ -11,6 +11,8 @@
 #include "als_device.hpp"
 #include "als_hip.h"
 
+extern "C" int als_gs_sweep(const als_gs_sweep_params* p, void* stream);
+
 namespace {
 
 template <int KB>
@@ -138,6 +140,20 @@ int launch_gs(const als_gs_sweep_params* p, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int als_gs_sweep_levels(const als_gs_sweep_params* p, const int64_t* level_offsets,
+                                   int64_t nlevels, void* stream) {
+    if (!p || nlevels < 0 || (nlevels > 0 && (!level_offsets || !p->items))) return ALS_E_BADARG;
+    for (int64_t l = 0; l < nlevels; ++l) {
+        als_gs_sweep_params q = *p;
+        q.items = p->items + level_offsets[l];
+        q.nitems = level_offsets[l + 1] - level_offsets[l];
+        if (q.nitems < 0) return ALS_E_BADARG;
+        const int rc = als_gs_sweep(&q, stream);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
 
 extern "C" int als_gs_sweep(const als_gs_sweep_params* p, void* stream) {
     if (!p) return ALS_E_BADARG;

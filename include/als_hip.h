@@ -160,6 +160,12 @@ typedef struct als_gs_sweep_params {
 
 int als_gs_sweep(const als_gs_sweep_params* p, void* stream);
 
+/* Whole sweep in one call: level l covers p->items[level_offsets[l] .. level_offsets[l+1]) (host
+ * array of nlevels+1 offsets into the device array p->items; p->nitems is ignored).  One launch per
+ * level on `stream`; levels are dependent, so stream order is the synchronisation. */
+int als_gs_sweep_levels(const als_gs_sweep_params* p, const int64_t* level_offsets /* host */,
+                        int64_t nlevels, void* stream);
+
 /* ---------------------------------------------------------------------------
  * als_residual_stats - replaces scripts/als.py:503-512: one pass over the
  * ratings (CSR) computing sum(d) and sum(d^2), d = r - (U_u.Z_i + b_u + b_i
