@@ -16,7 +16,7 @@ SPLIT_CHUNK = 4096          # ALS_SPLIT_CHUNK
 MAX_K = 160                 # ALS_MAX_K
 
 EXPORTS = ("als_version", "als_padded_k", "als_perm_index", "als_partial_slot_bytes",
-           "als_row_solve", "als_gs_sweep", "als_gs_sweep_levels", "als_residual_stats", "als_sumsq_partials",
+           "als_row_solve", "als_gs_sweep", "als_gs_sweep_levels", "als_residual_stats", "als_sum_pairs", "als_sumsq_partials",
            "als_sumsq", "als_compose_z", "als_predict_at", "als_predict_dense")
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -32,7 +32,8 @@ class RowSolveParams(C.Structure):
         ("lambda_bias_scalar", _f32), ("lambda_bias_row", _vp),
         ("rhs_extra", _vp), ("diag_extra", _vp),
         ("X_out", _vp), ("bias_out", _vp), ("gram_out", _vp), ("factor_out", _vp),
-        ("rhs_out", _vp), ("colsum_out", _vp), ("sumr_out", _vp), ("status", _vp),
+        ("rhs_out", _vp), ("colsum_out", _vp), ("sumr_out", _vp), ("sumr2_out", _vp), ("stat_out", _vp),
+        ("status", _vp),
         ("tasks", _vp), ("ntasks", _i64), ("long_rows", _vp), ("nlong", _i64),
         ("workspace", _vp),
     ]
@@ -45,7 +46,7 @@ class GsSweepParams(C.Structure):
         ("S_ptr", _vp), ("S_idx", _vp), ("S_val", _vp), ("alpha", _f32),
         ("factor", _vp), ("rhs", _vp), ("colsum", _vp), ("sumr", _vp),
         ("indptr", _vp), ("lambda_bias_scalar", _f32), ("lambda_bias_row", _vp),
-        ("V", _vp), ("bias", _vp),
+        ("V", _vp), ("bias", _vp), ("sumr2", _vp), ("lambda_eff", _vp), ("stat_out", _vp),
     ]
 
 
@@ -81,6 +82,7 @@ def load():
                                        _vp, _i64, _vp, _vp, _vp]
     lib.als_sumsq_partials.restype = C.c_int
     lib.als_sumsq.argtypes = [_vp, _i64, _vp, _vp, _vp]
+    lib.als_sum_pairs.argtypes = [_vp, _i64, _vp, _vp, _vp]
     lib.als_compose_z.argtypes = [_i64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
     lib.als_predict_at.argtypes = [C.c_int, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.als_predict_dense.argtypes = [C.c_int, C.c_int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]

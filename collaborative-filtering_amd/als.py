@@ -350,6 +350,14 @@ class _Engine:
         self.gram = (torch.zeros(n_pad, self.ld, self.ld, dtype=f32, device=device)
                      if self.feat_names else None)
 
+        # --- fused statistics (DESIGN.md "Statistics"): without features Z == V, so the residual
+        #     sums of an iteration follow in closed form from what the V-step already holds
+        self.fused_stats = (not self.feat_names) and self.ld <= 64 and hasattr(backend, "sum_pairs")
+        if self.fused_stats:
+            self.stat_rows = torch.zeros(n_pad, 2, dtype=f32, device=device)
+            if self.use_graph:
+                self.sumr2 = torch.zeros(n_pad, dtype=f32, device=device)
+                self.lam_eff = (self.lam_v_row + np.float32(EPS) + self.diag_extra).contiguous()
         # --- stats scratch
         self.stats = torch.zeros(2, dtype=f64, device=device)
         self.ss = torch.zeros(4, dtype=f64, device=device)
@@ -436,13 +444,15 @@ class _Engine:
             with self._tick("row_solve_item"):
                 self.be.row_solve(diag_extra=None, X_out=self.V, bias_out=self.b_i, factor_out=None,
                                   rhs_out=self.rhs_out if want_gram else None,
-                                  colsum_out=self.colsum_out if want_gram else None, sumr_out=None, **common)
+                                  colsum_out=self.colsum_out if want_gram else None, sumr_out=None,
+                                  stat_out=self.stat_rows if self.fused_stats else None, **common)
         else:
             # phase A (parallel): Gram, rhs, Cholesky factor of every item of the shard
             with self._tick("row_solve_item"):
                 self.be.row_solve(diag_extra=self.diag_extra, X_out=None, bias_out=None,
                                   factor_out=self.factor, rhs_out=self.rhs_out, colsum_out=self.colsum_out,
-                                  sumr_out=self.sumr, **common)
+                                  sumr_out=self.sumr, sumr2_out=self.sumr2 if self.fused_stats else None,
+                                  **common)
             # phase B (sequential in levels): Gauss-Seidel sweep with live V (:458)
             with self._tick("gs_sweep"):
                 self._gs_sweep()
@@ -457,6 +467,8 @@ class _Engine:
                   alpha=md.alpha, factor=self.factor, rhs=self.rhs_out, colsum=self.colsum_out,
                   sumr=self.sumr, indptr=self.csc.indptr, lam_b=md.lambda_bi, lam_b_row=None,
                   V=self.V, bias=self.b_i)
+        if self.fused_stats:
+            kw.update(sumr2=self.sumr2, lambda_eff=self.lam_eff, stat_out=self.stat_rows)
         if not exact_multi and hasattr(self.be, "gs_levels"):
             # no collective between levels: the whole sweep is one C call (one launch per level)
             self.be.gs_levels(offsets=np.ascontiguousarray(off, dtype=np.int64), items=self.sched_items, **kw)
@@ -560,8 +572,11 @@ class _Engine:
         if self.feat_names:
             self.be.compose_z(self.V, self.Xcat, self.Wcat, self.Z)              # :504
         with self._tick("residual_stats"):
-            self.be.residual_stats(k=self.k, ld=self.ld, side=self.csr, U=self.U, Z=self.Z, b_u=self.b_u,
-                                   b_i=self.b_i, mu=self.mu, tasks=self.utasks, out=self.stats)
+            if self.fused_stats:        # per-item (sum d, sum d^2) written by the V-step / the sweep
+                self.be.sum_pairs(self.stat_rows, self.stats)
+            else:
+                self.be.residual_stats(k=self.k, ld=self.ld, side=self.csr, U=self.U, Z=self.Z, b_u=self.b_u,
+                                       b_i=self.b_i, mu=self.mu, tasks=self.utasks, out=self.stats)
         self._allreduce(self.stats)
         for j, t in enumerate((self.U, self.V, self.b_u, self.b_i)):
             self.be.sumsq(t, self.ss[j:j + 1])

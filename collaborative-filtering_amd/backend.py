@@ -49,7 +49,7 @@ class HipBackend:
     # -- K1 ------------------------------------------------------------------
     def row_solve(self, *, k, ld, side, F, zero_row, bias_self, bias_other, mu, lam, lam_row, lam_b,
                   lam_b_row, rhs_extra, diag_extra, X_out, bias_out, gram_out, factor_out,
-                  rhs_out, colsum_out, sumr_out, status, tasks, workspace):
+                  rhs_out, colsum_out, sumr_out, status, tasks, workspace, sumr2_out=None, stat_out=None):
         p = _hip.RowSolveParams()
         p.k, p.ld, p.nrows, p.F_zero_row = k, ld, side.nrows, int(zero_row)
         p.reserved0 = self.ablate          # 0 in production; profiling builds of bench.py set it
@@ -60,6 +60,7 @@ class HipBackend:
         p.rhs_extra, p.diag_extra = _p(rhs_extra), _p(diag_extra)
         p.X_out, p.bias_out, p.gram_out, p.factor_out = _p(X_out), _p(bias_out), _p(gram_out), _p(factor_out)
         p.rhs_out, p.colsum_out, p.sumr_out, p.status = _p(rhs_out), _p(colsum_out), _p(sumr_out), _p(status)
+        p.sumr2_out, p.stat_out = _p(sumr2_out), _p(stat_out)
         p.tasks, p.ntasks = _p(tasks.tasks), tasks.ntasks
         p.long_rows, p.nlong = _p(tasks.long_rows), tasks.nlong
         p.workspace = _p(workspace)
@@ -67,8 +68,9 @@ class HipBackend:
 
     # -- K2 ------------------------------------------------------------------
     def gs_level(self, *, k, ld, items, S_ptr, S_idx, S_val, alpha, factor, rhs, colsum, sumr,
-                 indptr, lam_b, lam_b_row, V, bias):
+                 indptr, lam_b, lam_b_row, V, bias, sumr2=None, lambda_eff=None, stat_out=None):
         p = _hip.GsSweepParams()
+        p.sumr2, p.lambda_eff, p.stat_out = _p(sumr2), _p(lambda_eff), _p(stat_out)
         p.k, p.ld = k, ld
         p.items, p.nitems = _p(items), items.numel()
         p.S_ptr, p.S_idx, p.S_val, p.alpha = _p(S_ptr), _p(S_idx), _p(S_val), float(alpha)
@@ -87,6 +89,7 @@ class HipBackend:
         p.factor, p.rhs, p.colsum, p.sumr = _p(kw["factor"]), _p(kw["rhs"]), _p(kw["colsum"]), _p(kw["sumr"])
         p.indptr, p.lambda_bias_scalar, p.lambda_bias_row = _p(kw["indptr"]), float(kw["lam_b"]), _p(kw["lam_b_row"])
         p.V, p.bias = _p(kw["V"]), _p(kw["bias"])
+        p.sumr2, p.lambda_eff, p.stat_out = _p(kw.get("sumr2")), _p(kw.get("lambda_eff")), _p(kw.get("stat_out"))
         off = offsets.ctypes.data_as(C.c_void_p)
         self._check(self.lib.als_gs_sweep_levels(C.byref(p), off, len(offsets) - 1, self._stream()),
                     "als_gs_sweep_levels")
@@ -103,6 +106,12 @@ class HipBackend:
             k, ld, _p(side.indptr), _p(side.indices), _p(side.vals), _p(U), _p(Z), _p(b_u), _p(b_i),
             _p(mu), _p(tasks.tasks), tasks.ntasks, _p(self._stats_partials), _p(out), self._stream()),
             "als_residual_stats")
+
+    def sum_pairs(self, x: torch.Tensor, out: torch.Tensor):
+        """out[0:2] = column sums of x viewed as [n, 2] (fp64, deterministic)."""
+        part = torch.empty(2 * self._sumsq_partials.numel(), dtype=torch.float64, device=self.device)
+        self._check(self.lib.als_sum_pairs(_p(x), x.numel() // 2, _p(part), _p(out), self._stream()),
+                    "als_sum_pairs")
 
     def sumsq(self, x: torch.Tensor, out: torch.Tensor):
         self._check(self.lib.als_sumsq(_p(x), x.numel(), _p(self._sumsq_partials), _p(out),

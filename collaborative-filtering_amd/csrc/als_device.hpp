@@ -84,7 +84,7 @@ struct KCfg {
     // waves per workgroup / minimum waves per SIMD asked of the register allocator
     static constexpr int WPW = (KB <= 4) ? 4 : (KB <= 6 ? 2 : 1);
     static constexpr int MINW = (KB <= 4) ? 3 : 1;
-    static constexpr int SLOT_ITEMS = NACC * 4 + 2 * KB + 1;  // per-lane floats of a partial
+    static constexpr int SLOT_ITEMS = NACC * 4 + 2 * KB + 2;  // per-lane floats of a partial
     // gather steps (4 ratings each) staged in registers at a time
     static constexpr int GS = (KB <= 8) ? 8 : 4;
 };
@@ -98,7 +98,8 @@ struct KCfg {
 // right-hand side pre-scaled by di so that each of the 2*KP dependent steps is
 // one v_readlane + one v_fma.
 template <int KP>
-__device__ __forceinline__ float solve_regs(const float (&a)[KP], float di, float rb, int lane) {
+__device__ __forceinline__ float solve_regs(const float (&a)[KP], float di, float rb, int lane,
+                                            float* y_out = nullptr) {
     float rs = rb * di;
 #pragma unroll
     for (int j = 0; j < KP; ++j) {
@@ -106,7 +107,8 @@ __device__ __forceinline__ float solve_regs(const float (&a)[KP], float di, floa
         const float cf = (lane > j) ? a[j] * di : 0.f;
         rs = fmaf(-cf, yj, rs);
     }
-    rs *= di;   // lane j now holds y_j; rescale for the transposed sweep
+    if (y_out) *y_out = rs;   // lane j holds y_j of L y = b
+    rs *= di;   // rescale for the transposed sweep
 #pragma unroll
     for (int i = KP - 1; i >= 0; --i) {
         const float xi = readlane_f(rs, i);

@@ -86,14 +86,33 @@ void k_gs_level(const als_gs_sweep_params P) {
 
     if constexpr (KB <= 4) {
         const float rb = rhs_i + P.alpha * g[0];
-        const float x = solve_regs<KP>(a, di, rb, lane);
-        float dot = 0.f;
+        float y = 0.f;
+        const float x = solve_regs<KP>(a, di, rb, lane, &y);
+        float dot = 0.f, xr = 0.f, yy = 0.f, xx = 0.f;
         if (lane < KP) {
             P.V[i64 * P.ld + col[0]] = x;
             dot = cs_i * x;
+            xr = rhs_i * x;
+            yy = y * y;
+            xx = x * x;
         }
         dot = wave_sum(dot);
-        if (lane == 0) P.bias[item] = (P.sumr[item] - dot) / (nnz + lb + ALS_EPS);
+        const float bnew = (P.sumr[item] - dot) / (nnz + lb + ALS_EPS);
+        const float bold = P.bias[item];
+        __builtin_amdgcn_sched_barrier(0);
+        if (lane == 0) P.bias[item] = bnew;
+        if (P.stat_out) {       // closed-form residual sums of this item (see row_solve.hip)
+            xr = wave_sum(xr); yy = wave_sum(yy); xx = wave_sum(xx);
+            if (lane == 0) {
+                const float sumr = P.sumr[item], sumr2 = P.sumr2[item];
+                const float s1 = sumr - nnz * bnew;
+                const float s2 = sumr2 - 2.f * bnew * sumr + nnz * bnew * bnew;
+                const float cross = xr + (bold - bnew) * dot;
+                const float quad = yy - P.lambda_eff[item] * xx;
+                P.stat_out[2 * i64] = s1 - dot;
+                P.stat_out[2 * i64 + 1] = s2 - 2.f * cross + quad;
+            }
+        }
     } else {
         float* Al = lds_all + wave * IMG;
         float* vec = Al + KP * LD;
@@ -163,6 +182,7 @@ extern "C" int als_gs_sweep(const als_gs_sweep_params* p, void* stream) {
         !p->sumr || !p->indptr || !p->V || !p->bias)
         return ALS_E_BADARG;
     if (p->nitems > 0 && !p->items) return ALS_E_BADARG;
+    if (p->stat_out && (!p->sumr2 || !p->lambda_eff || ld > 64)) return ALS_E_BADARG;   // fused stats: k <= 64
     hipStream_t st = (hipStream_t)stream;
     switch (ld / 16) {
         case 1: return launch_gs<1>(p, st);

@@ -32,12 +32,13 @@ struct RowAcc {
     float rhs[KB];
     float cs[KB];
     float sumr;
+    float sumr2;
     __device__ __forceinline__ void zero() {
 #pragma unroll
         for (int a = 0; a < KCfg<KB>::NACC; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int b = 0; b < KB; ++b) { rhs[b] = 0.f; cs[b] = 0.f; }
-        sumr = 0.f;
+        sumr = 0.f; sumr2 = 0.f;
     }
 };
 
@@ -114,6 +115,7 @@ __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __
         const bool ok = lane < nvalid;
         const float rb = val0 - mu - bo0;
         A.sumr += ok ? rb : 0.f;
+        A.sumr2 = ok ? fmaf(rb, rb, A.sumr2) : A.sumr2;
         const float r0 = ok ? (rb - bself) : 0.f;
         const int off0 = idx0 * ld;                       // < 2^31 elements (checked by the launcher)
         if (nvalid == 64) process_chunk<KB, true>(A, off0, r0, 64, Fc, q);
@@ -135,7 +137,8 @@ __device__ __forceinline__ void store_partial(const RowAcc<KB>& A, float* __rest
     for (int b = 0; b < KB; ++b) ws[(it++) * 64 + lane] = A.rhs[b];
 #pragma unroll
     for (int b = 0; b < KB; ++b) ws[(it++) * 64 + lane] = A.cs[b];
-    ws[it * 64 + lane] = A.sumr;
+    ws[(it++) * 64 + lane] = A.sumr;
+    ws[it * 64 + lane] = A.sumr2;
 }
 
 template <int KB>
@@ -149,7 +152,8 @@ __device__ __forceinline__ void add_partial(RowAcc<KB>& A, const float* __restri
     for (int b = 0; b < KB; ++b) A.rhs[b] += ws[(it++) * 64 + lane];
 #pragma unroll
     for (int b = 0; b < KB; ++b) A.cs[b] += ws[(it++) * 64 + lane];
-    A.sumr += ws[it * 64 + lane];
+    A.sumr += ws[(it++) * 64 + lane];
+    A.sumr2 += ws[it * 64 + lane];
 }
 
 // ---------------------------------------------------------------------------
@@ -343,6 +347,7 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
         A.cs[b] += __shfl_xor(A.cs[b], 16, 64);   A.cs[b] += __shfl_xor(A.cs[b], 32, 64);
     }
     const float sumr = wave_sum(A.sumr);
+    const float sumr2 = wave_sum(A.sumr2);
 
     // perm position i = lane + 64 rr is block (q + 4 rr), position c: the lane already holds it
     Chol<KB> S;
@@ -385,6 +390,7 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
         }
     }
     if (P.sumr_out && lane == 0) P.sumr_out[row] = sumr;
+    if (P.sumr2_out && lane == 0) P.sumr2_out[row] = sumr2;
 
     // regulariser on the diagonal (C/D layout: diagonal where 4q + r == c); padded columns get 1
     const float lam = (P.lambda_row ? P.lambda_row[row] : P.lambda_scalar) + ALS_EPS
@@ -420,6 +426,9 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
         return;
     }
 
+    float rhs0[NR];                         // F^T r before any extra right-hand side (statistics)
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) rhs0[rr] = S.b[rr];
     if (P.rhs_extra) {
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr)
@@ -434,19 +443,38 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
         for (int rr = 0; rr < NR; ++rr) x[rr] = S.y[rr];
     }
 
-    float dot = 0.f;
+    float dot = 0.f, xr = 0.f, yy = 0.f, xx = 0.f;
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
         if (lane + 64 * rr < KP) {
             P.X_out[r64 * P.ld + colrow[rr]] = x[rr];
             dot = fmaf(csrow[rr], x[rr], dot);
+            xr = fmaf(rhs0[rr], x[rr], xr);
+            yy = fmaf(S.y[rr], S.y[rr], yy);
+            xx = fmaf(x[rr], x[rr], xx);
         }
     }
     dot = wave_sum(dot);
-    if (lane == 0) {
-        const float nnz = (float)(P.indptr[row + 1] - P.indptr[row]);
-        const float lb = P.lambda_bias_row ? P.lambda_bias_row[row] : P.lambda_bias_scalar;
-        P.bias_out[row] = (sumr - dot) / (nnz + lb + ALS_EPS);
+    const float nnz = (float)(P.indptr[row + 1] - P.indptr[row]);
+    const float lb = P.lambda_bias_row ? P.lambda_bias_row[row] : P.lambda_bias_scalar;
+    const float bnew = (sumr - dot) / (nnz + lb + ALS_EPS);
+    const float bold = P.bias_self[row];            // read before the store: bias_out may alias bias_self
+    __builtin_amdgcn_sched_barrier(0);
+    if (lane == 0) P.bias_out[row] = bnew;
+    if (P.stat_out) {
+        // residuals of this row with the new x and bias, in closed form (DESIGN.md "Statistics"):
+        //   sum d   = sum rho - nnz b - (F^T 1).x
+        //   sum d^2 = sum (rho - b)^2 - 2 x.F^T(rho - b) + x^T G x,   x^T G x = |y|^2 - lambda |x|^2
+        xr = wave_sum(xr); yy = wave_sum(yy); xx = wave_sum(xx);
+        if (lane == 0) {
+            // rhs0 was formed with the old bias (bold)
+            const float s1 = sumr - nnz * bnew;
+            const float s2 = sumr2 - 2.f * bnew * sumr + nnz * bnew * bnew;
+            const float cross = xr + (bold - bnew) * dot;
+            const float quad = yy - lam * xx;
+            P.stat_out[2 * r64] = s1 - dot;
+            P.stat_out[2 * r64 + 1] = s2 - 2.f * cross + quad;
+        }
     }
 }
 
@@ -529,7 +557,7 @@ extern "C" int64_t als_partial_slot_bytes(int k) {
     const int ld = als_padded_k(k);
     if (ld < 0) return ALS_E_BADK;
     const int KB = ld / 16;
-    return (int64_t)(KB * (KB + 1) / 2 * 4 + 2 * KB + 1) * 64 * sizeof(float);
+    return (int64_t)(KB * (KB + 1) / 2 * 4 + 2 * KB + 2) * 64 * sizeof(float);
 }
 
 extern "C" int als_row_solve(const als_row_solve_params* p, void* stream) {

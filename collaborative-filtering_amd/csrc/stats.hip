@@ -121,6 +121,29 @@ void k_sumsq_partial(const float* __restrict__ x, int64_t n, double* __restrict_
     if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
 }
 
+__global__ __launch_bounds__(256)
+void k_sum_pairs_partial(const float* __restrict__ x, int64_t npairs, double* __restrict__ partials) {
+    __shared__ double red[512];
+    double a = 0.0, b = 0.0;
+    const f32x2* x2 = reinterpret_cast<const f32x2*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npairs; i += (int64_t)gridDim.x * 256) {
+        const f32x2 v = x2[i];
+        a += (double)v.x;
+        b += (double)v.y;
+    }
+    red[threadIdx.x] = a;
+    red[256 + threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            red[threadIdx.x] += red[threadIdx.x + o];
+            red[256 + threadIdx.x] += red[256 + threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = red[0]; partials[2 * blockIdx.x + 1] = red[256]; }
+}
+
 template <int KB>
 int launch_stats(int ld, const int64_t* indptr, const int32_t* indices, const float* vals,
                  const float* U, const float* Z, const float* b_u, const float* b_i,
@@ -154,6 +177,17 @@ extern "C" int als_residual_stats(int k, int ld, const int64_t* indptr, const in
     }
 #undef ALS_STATS_CASE
     return ALS_E_BADK;
+}
+
+extern "C" int als_sum_pairs(const float* x, int64_t npairs, double* partials, double* out, void* stream) {
+    if (!x || npairs < 0 || !partials || !out || ((uintptr_t)x & 7) != 0) return ALS_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    int64_t nblk = (npairs + 255) / 256;
+    if (nblk < 1) nblk = 1;
+    if (nblk > SUMSQ_BLOCKS) nblk = SUMSQ_BLOCKS;
+    hipLaunchKernelGGL(k_sum_pairs_partial, dim3((unsigned)nblk), dim3(256), 0, st, x, npairs, partials);
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, st, partials, nblk, 2, out);
+    return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
 }
 
 extern "C" int als_sumsq_partials(void) { return SUMSQ_BLOCKS; }

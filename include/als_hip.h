@@ -91,7 +91,9 @@ int64_t als_partial_slot_bytes(int k);
  *   rhs_out    [nrows][ld]    F^T r (perm space, without rhs_extra),
  *   colsum_out [nrows][ld]    sum_t F_t (perm space),
  *   sumr_out   [nrows]        sum_t(vals[t] - mu - bias_other[indices[t]])
+ *   sumr2_out  [nrows]        sum_t(vals[t] - mu - bias_other[indices[t]])^2
  *                             (each written when its pointer is non-NULL)
+ *   stat_out   [nrows][2]     solve mode only: (sum d, sum d^2) of the row's residuals after the update
  *   factor-only mode (factor_out != NULL): nothing is solved; instead
  *     factor_out [nrows][ld][ld] symmetric completion of the Cholesky factor
  *                               L (perm space) with 1/L_ii on the diagonal
@@ -129,6 +131,10 @@ typedef struct als_row_solve_params {
     float*         rhs_out;
     float*         colsum_out;
     float*         sumr_out;
+    float*         sumr2_out;           /* nullable [nrows]: sum_t (vals[t]-mu-bias_other)^2 (factor-only mode) */
+    float*         stat_out;            /* nullable [nrows][2]: (sum d, sum d^2) of the row with the NEW x and
+                                           bias, d = vals - F_t.x - mu - bias_other - bias_new; lets the caller
+                                           skip als_residual_stats when Z == F-side of the other step */
     int32_t*       status;
     const als_task*     tasks;      int64_t ntasks;
     const als_long_row* long_rows;  int64_t nlong;
@@ -156,6 +162,10 @@ typedef struct als_gs_sweep_params {
     float lambda_bias_scalar;  const float* lambda_bias_row;
     float* V;                            /* [n][ld], updated in place */
     float* bias;                         /* [n] */
+    /* optional fused statistics (all three or none): */
+    const float* sumr2;                  /* [n] from als_row_solve (sumr2_out) */
+    const float* lambda_eff;             /* [n] total diagonal shift used in the factor (lambda+1e-10+diag_extra) */
+    float* stat_out;                     /* [n][2]: (sum d, sum d^2) with the new V[i], bias[i] */
 } als_gs_sweep_params;
 
 int als_gs_sweep(const als_gs_sweep_params* p, void* stream);
@@ -177,6 +187,10 @@ int als_residual_stats(int k, int ld, const int64_t* indptr, const int32_t* indi
                        const float* b_u, const float* b_i, const double* mu,
                        const als_task* tasks, int64_t ntasks,
                        double* partials, double* out, void* stream);
+
+/* out[0] = sum_i x[2i], out[1] = sum_i x[2i+1] in fp64 (reduction of stat_out).
+ * partials: scratch of 2*als_sumsq_partials() doubles. */
+int als_sum_pairs(const float* x, int64_t npairs, double* partials, double* out, void* stream);
 
 /* sum of squares of a float array in fp64 (scripts/als.py:514-517 norms).
  * partials: scratch of als_sumsq_partials() doubles. out: device double. */

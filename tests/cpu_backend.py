@@ -30,7 +30,7 @@ class NumpyBackend:
 
     def slot_bytes(self, k):
         kb = layout.padded_k(k) // 16
-        return (kb * (kb + 1) // 2 * 4 + 2 * kb + 1) * 64 * 4
+        return (kb * (kb + 1) // 2 * 4 + 2 * kb + 2) * 64 * 4
 
     @staticmethod
     def _rows(tasks):
@@ -39,7 +39,7 @@ class NumpyBackend:
 
     def row_solve(self, *, k, ld, side, F, zero_row, bias_self, bias_other, mu, lam, lam_row, lam_b, lam_b_row,
                   rhs_extra, diag_extra, X_out, bias_out, gram_out, factor_out, rhs_out, colsum_out,
-                  sumr_out, status, tasks, workspace):
+                  sumr_out, status, tasks, workspace, sumr2_out=None, stat_out=None):
         ptr, idx, vals = _np(side.indptr), _np(side.indices), _np(side.vals)
         # zero_row indexes the extra all-zero row behind the [rows_pad, ld] view; unused here
         Fn = _np(F)[:, :k].astype(self.dtype)
@@ -70,6 +70,8 @@ class NumpyBackend:
                 t = np.zeros(ld, dtype=np.float32); t[pos[:k]] = cs; colsum_out[r] = torch.from_numpy(t)
             if sumr_out is not None:
                 sumr_out[r] = float(base.sum())
+            if sumr2_out is not None:
+                sumr2_out[r] = float((base * base).sum())
             A = G + lam_r * np.eye(k)
             try:
                 L = np.linalg.cholesky(A)
@@ -90,10 +92,14 @@ class NumpyBackend:
             xo = np.zeros(ld, dtype=np.float32); xo[:k] = x
             X_out[r] = torch.from_numpy(xo)
             lb = float(lam_b_row[r]) if lam_b_row is not None else float(lam_b)
-            bias_out[r] = float((base.sum() - cs @ x) / ((hi - lo) + lb + EPS))
+            bnew = float((base.sum() - cs @ x) / ((hi - lo) + lb + EPS))
+            bias_out[r] = bnew
+            if stat_out is not None:          # residuals with the new x / bias, computed directly
+                d = base - Fr @ x - bnew
+                stat_out[r, 0] = float(d.sum()); stat_out[r, 1] = float((d * d).sum())
 
     def gs_level(self, *, k, ld, items, S_ptr, S_idx, S_val, alpha, factor, rhs, colsum, sumr, indptr,
-                 lam_b, lam_b_row, V, bias):
+                 lam_b, lam_b_row, V, bias, sumr2=None, lambda_eff=None, stat_out=None):
         pos = layout.perm_of_col(k)
         sp, si, sv = _np(S_ptr), _np(S_idx), _np(S_val)
         ptr = _np(indptr)
@@ -110,11 +116,24 @@ class NumpyBackend:
             xp = np.linalg.solve(L.T, np.linalg.solve(L, b))
             x = xp[pos[:k]]
             lb = float(lam_b_row[i]) if lam_b_row is not None else float(lam_b)
-            new[int(i)] = (x, (float(sumr[i]) - _np(colsum)[i].astype(np.float64) @ xp)
-                           / ((ptr[i + 1] - ptr[i]) + lb + EPS))
-        for i, (x, bv) in new.items():       # a level's items never neighbour each other
+            nnz = ptr[i + 1] - ptr[i]
+            csp = _np(colsum)[i].astype(np.float64)
+            bnew = (float(sumr[i]) - csp @ xp) / (nnz + lb + EPS)
+            st = None
+            if stat_out is not None:          # the closed form the kernel uses (no ratings at hand here)
+                y = np.linalg.solve(L, b)
+                bold = float(bias[i])
+                s1 = float(sumr[i]) - nnz * bnew
+                s2 = float(sumr2[i]) - 2 * bnew * float(sumr[i]) + nnz * bnew * bnew
+                cross = _np(rhs)[i].astype(np.float64) @ xp + (bold - bnew) * (csp @ xp)
+                quad = y @ y - float(lambda_eff[i]) * (xp @ xp)
+                st = (s1 - csp @ xp, s2 - 2 * cross + quad)
+            new[int(i)] = (x, bnew, st)
+        for i, (x, bv, st) in new.items():       # a level's items never neighbour each other
             V[i, :k] = torch.from_numpy(x.astype(np.float32))
             bias[i] = float(bv)
+            if st is not None:
+                stat_out[i, 0], stat_out[i, 1] = float(st[0]), float(st[1])
 
     def residual_stats(self, *, k, ld, side, U, Z, b_u, b_i, mu, tasks, out):
         ptr, idx, vals = _np(side.indptr), _np(side.indices), _np(side.vals)
@@ -127,6 +146,9 @@ class NumpyBackend:
             d = vals[ptr[r]:ptr[r + 1]] - (Zn[cols] @ Un[r] + bu[r] + bi[cols] + mu)
             sd += d.sum(); sd2 += (d * d).sum()
         out[0], out[1] = sd, sd2
+
+    def sum_pairs(self, x, out):
+        out.copy_(x.view(-1, 2).double().sum(0))
 
     def sumsq(self, x, out):
         out[0] = float((x.double() ** 2).sum())

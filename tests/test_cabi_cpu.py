@@ -37,7 +37,7 @@ def test_host_side_queries(lib):
         assert sorted(perm) == list(range(ld))
         assert perm == list(layout.perm_of_col(k))
         kb = ld // 16
-        assert lib.als_partial_slot_bytes(k) == (kb * (kb + 1) // 2 * 4 + 2 * kb + 1) * 64 * 4
+        assert lib.als_partial_slot_bytes(k) == (kb * (kb + 1) // 2 * 4 + 2 * kb + 2) * 64 * 4
     assert lib.als_padded_k(0) == -2 and lib.als_padded_k(161) == -2
 
 

@@ -109,3 +109,21 @@ def test_three_ranks_uneven_shards():
         np.testing.assert_array_equal(outs[0]["U"], outs[r]["U"])
     np.testing.assert_array_equal(outs[0]["U"], ref.U)
     np.testing.assert_array_equal(outs[0]["V"], ref.V)
+
+
+def test_fused_statistics_closed_form_on_cpu():
+    """Graph on, no features: the engine takes mu / RMSE from the per-item closed form (stand-in
+    implements the same formula as the sweep kernel) - must equal the standalone residual pass."""
+    from tests.common import Golden
+    from tests.cpu_backend import NumpyBackend
+    from tests.test_gpu_parity import _model_for
+
+    NoFuse = type("NoFuse", (object,), {k: v for k, v in NumpyBackend.__dict__.items() if k != "sum_pairs"})
+
+    g = Golden("g5_graph_a0.5")
+    r, c, v = g.train
+    a = _model_for(g, device="cpu", backend=NumpyBackend()).fit_coo(r, c, v, (g.m, g.n), tol=None, verbose=0, S=g.S_csr())
+    b = _model_for(g, device="cpu", backend=NoFuse()).fit_coo(r, c, v, (g.m, g.n), tol=None, verbose=0, S=g.S_csr())
+    assert a._eng.fused_stats and not b._eng.fused_stats
+    np.testing.assert_allclose(a.history["train_rmse"], b.history["train_rmse"], rtol=1e-6)
+    np.testing.assert_allclose(a.V, b.V, rtol=1e-5, atol=1e-7)

@@ -129,3 +129,46 @@ def test_run_to_run_bitwise_reproducible():
     b = _model_for(g).fit_coo(r, c, v, (g.m, g.n), tol=None, verbose=0)
     assert np.array_equal(a.U, b.U) and np.array_equal(a.V, b.V)
     assert a.history["train_rmse"] == b.history["train_rmse"]
+
+
+@pytest.mark.parametrize("name", ["g5_graph_a0.5", "g5_graph_a5.0"])
+def test_graph_without_features_matches_oracle(name):
+    """Laplacian on, no feature projections (the benchmark configuration): the statistics come from
+    the closed form fused into the sweep (DESIGN.md 'Statistics'); checked against the oracle run on
+    the same inputs with the fixture's pinned graph."""
+    _cuda()
+    from oracle.als_oracle import OracleALS
+    g = Golden(name)
+    r, c, v = g.train
+    cfg = g.oracle_config()
+    cfg.lambda_w = {}
+    o = OracleALS(cfg).fit(g.train_ratings(), {}, tol=None, S_csr=g.S_csr())
+    m = _model_for(g)
+    m.fit_coo(r, c, v, (g.m, g.n), features=None, tol=None, verbose=0, S=g.S_csr())
+    assert m._eng.fused_stats and m._eng.use_graph
+    assert np.max(np.abs(np.asarray(m.history["train_rmse"]) - np.asarray(o.history["train_rmse"]))) <= 2e-5
+    _close(m.V, o.V, what="V")
+    _close(m.U, o.U, what="U")
+    assert abs(m.mu - o.mu) <= 2e-5
+
+
+def test_fused_statistics_equal_the_standalone_pass():
+    """Same fit with the fused statistics switched off (standalone als_residual_stats pass)."""
+    _cuda()
+    g = Golden("g9_k64_mid")
+    r, c, v = g.train
+    a = _model_for(g).fit_coo(r, c, v, (g.m, g.n), tol=None, verbose=0)
+    assert a._eng.fused_stats
+    import collaborative_filtering_amd.als as A
+    orig = A._Engine.stats_step
+
+    def unfused(self, it):
+        self.fused_stats = False
+        return orig(self, it)
+    A._Engine.stats_step = unfused
+    try:
+        b = _model_for(g).fit_coo(r, c, v, (g.m, g.n), tol=None, verbose=0)
+    finally:
+        A._Engine.stats_step = orig
+    np.testing.assert_allclose(a.history["train_rmse"], b.history["train_rmse"], atol=3e-6, rtol=0)
+    assert abs(a.mu - b.mu) <= 3e-6
