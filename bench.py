@@ -204,6 +204,9 @@ def main():
     ap.add_argument("--gs-mode", default=None, choices=[None, "exact", "block"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="debug only; not a valid headline run")
+    ap.add_argument("--gram", default="bf16x3", choices=["bf16x3", "f32"],
+                    help="how K1 forms the Gram: exact 3-way bf16 split on the bf16 matrix cores (fp32 "
+                         "accumulate, fp32-level accuracy) or v_mfma_f32 on the raw floats")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 code path with several ranks on ONE GPU")
     args = ap.parse_args()
@@ -257,7 +260,7 @@ def main():
                     biases=BiasesConfig(lambda_bu=3.0, lambda_bi=2.0),
                     graph=(GraphConfig(alpha=0.5, sim=GraphSimConfig(source="precomputed", topk=50))
                            if S is not None else GraphConfig()))
-    model = ALS(cfg, device=dev, gs_mode=args.gs_mode)
+    model = ALS(cfg, device=dev, gs_mode=args.gs_mode, gram=args.gram)
     eng = model.prepare_csr(csr, csc, (m, n), S=S)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
@@ -304,6 +307,8 @@ def main():
         n_launch = 2
         roof = {"kernel": "k_row_tasks<KB=4> (als_row_solve; U-step and V-step launches)",
                 "bound": "mfma", "achieved": fl / t_rs / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                "peak_note": "dense fp32 matrix peak (the arithmetic is fp32-equivalent; in gram=bf16x3 mode the "
+                             "Gram issues 6 bf16 MFMAs per block on the 2.5 PFLOP/s bf16 pipe instead)",
                 "frac": fl / t_rs / 1e12 / 157.3,
                 "avg_launch_ms": 1e3 * t_rs / n_launch,
                 "algorithmic_flops_per_launch": fl / n_launch,
@@ -324,11 +329,12 @@ def main():
             "metric": "ratings/sec per ALS iteration at k=64", "value": nnz / (elapsed / args.steps),
             "unit": "ratings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": ("f32 (storage, solve, accumulate); Gram products as exact 3-way bf16 split on bf16 MFMA"
+                      if args.gram == "bf16x3" else "f32"), "data": "synthetic",
             "config": {"workload": f"{args.size}: {m} users x {n} items, {nnz} ratings, k={k}, bias + "
                                    f"graph-Laplacian (alpha=0.5, {0 if S is None else int(S[1].numel())} graph nnz)"
                                    f" [BASELINE.json configs[3]]",
-                       "gs_mode": getattr(eng, "gs_mode", None), "gs_levels": (len(eng.sched.offsets) - 1)
+                       "gram": args.gram, "gs_mode": getattr(eng, "gs_mode", None), "gs_levels": (len(eng.sched.offsets) - 1)
                        if eng.use_graph else 0,
                        "parallelism": f"users/items sharded x{world}, all-gather of factor blocks",
                        "setup_s": t_setup},

@@ -9,7 +9,7 @@ per-row / per-rating step runs in the HIP kernels behind include/als_hip.h.
 
 Build-only additions (keyword arguments with defaults, so the reference
 signature is unchanged):
-  ALS(..., device=, backend=, gs_mode=, process_group=)
+  ALS(..., device=, backend=, gs_mode=, process_group=, gram=)
   fit(..., S=)              precomputed similarity graph as CSR (ptr, idx, val)
   fit_coo(rows, cols, vals, shape, ...)   sparse-native entry for large inputs
   predict_at(flat_idx, ...) predictions at flat indices u*n+i without the
@@ -91,7 +91,8 @@ class ALS:
     Laplacian:  R ~ U (V + sum_f X_f W_f)^T + mu + b_u + b_i."""
 
     def __init__(self, config: ALSConfig, lambda_w: Optional[Dict[str, float]] = None, *,
-                 device=None, backend=None, gs_mode: Optional[str] = None, process_group=None) -> None:
+                 device=None, backend=None, gs_mode: Optional[str] = None, process_group=None,
+                 gram: Optional[str] = None) -> None:
         if config is None:                                   # scripts/als.py:146-147
             raise ValueError("ALSConfig must be provided.")
         self.cfg = config
@@ -122,6 +123,7 @@ class ALS:
         self._backend = backend
         self._gs_mode = gs_mode
         self._pg = process_group
+        self._gram = gram               # "bf16x3" (default) or "f32": how K1 forms the Gram on the matrix cores
         self._eng: Optional[_Engine] = None
 
     # ------------------------------------------------------------------ fit
@@ -195,7 +197,7 @@ class ALS:
         backend = self._backend
         if backend is None:
             from .backend import HipBackend
-            backend = HipBackend(device)
+            backend = HipBackend(device, gram=self._gram or "bf16x3")
         self._eng = _Engine(self, csr, csc, features, S_csr, device, backend, self._pg, self._gs_mode)
         if not run:                         # prepare(): the caller drives the iterations
             return self

@@ -23,7 +23,12 @@ def _p(t: Optional[torch.Tensor]):
 class HipBackend:
     name = "hip"
 
-    def __init__(self, device: torch.device):
+    GRAM_MODES = {"f32": 0, "bf16x3": 1}
+
+    def __init__(self, device: torch.device, gram: str = "bf16x3"):
+        if gram not in self.GRAM_MODES:
+            raise ValueError(f"gram must be one of {sorted(self.GRAM_MODES)}")
+        self.gram_mode = self.GRAM_MODES[gram]
         if device.type != "cuda":
             raise RuntimeError("HipBackend needs a ROCm device (torch device type 'cuda'); "
                                "there is no CPU path in the product")
@@ -53,6 +58,7 @@ class HipBackend:
         p = _hip.RowSolveParams()
         p.k, p.ld, p.nrows, p.F_zero_row = k, ld, side.nrows, int(zero_row)
         p.reserved0 = self.ablate          # 0 in production; profiling builds of bench.py set it
+        p.gram_mode = self.gram_mode
         p.indptr, p.indices, p.vals = _p(side.indptr), _p(side.indices), _p(side.vals)
         p.F, p.bias_self, p.bias_other, p.mu = _p(F), _p(bias_self), _p(bias_other), _p(mu)
         p.lambda_scalar, p.lambda_row = float(lam), _p(lam_row)

@@ -81,6 +81,7 @@ struct KCfg {
     static constexpr int lcol_off(int J) { return 16 * (J * KP - 8 * J * (J - 1)); }
     __device__ static __forceinline__ int lcol_off_rt(int J) { return 16 * (J * KP - 8 * J * (J - 1)); }
     static constexpr int LDS_FLOATS = lcol_off(KB);   // 10 KB at k = 64
+    static_assert(lcol_off(KB) == NACC * 256, "the L image and a full accumulator set have the same size");
     // waves per workgroup / minimum waves per SIMD asked of the register allocator
     static constexpr int WPW = (KB <= 4) ? 4 : (KB <= 6 ? 2 : 1);
     static constexpr int MINW = (KB <= 4) ? 3 : 1;

@@ -88,14 +88,116 @@ __device__ __forceinline__ void process_chunk(RowAcc<KB>& A, int off_l, float r_
     }
 }
 
+// ---------------------------------------------------------------------------
+// Same 64 ratings on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16), fp32-equivalent.
+// Every gathered float is split EXACTLY into three bf16 terms by truncation,
+//     x = h + m + l,   h = top 16 bits of x,  m = top 16 bits of (x - h),  l = x - h - m
+// (l has at most 8 significant bits left, so it is representable), and the Gram block is
+// the sum of the six cross products hh + hm + mh + mm + hl + lh accumulated in fp32; the
+// three dropped ones (ml, lm, ll) are <= 2^-24 relative, i.e. at the fp32 rounding level.
+// bf16 MFMA runs beside the VALU (f32 MFMA does not - DESIGN.md section 4), the splitting
+// arithmetic is the VALU's share.  Lane (c,q) now takes ratings 8q..8q+7 of a 32-rating
+// group: the 8 values it loads per block are exactly its 8 k-elements of the A/B operand.
+// ---------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int pack_hi16(float hi_src, float lo_src) {     // {hi_src[31:16], lo_src[31:16]}
+    return __builtin_amdgcn_perm(__float_as_int(hi_src), __float_as_int(lo_src), 0x07060302);
+}
+
+template <int KB, bool FULL>
+__device__ __forceinline__ void process_chunk_bf16x3(RowAcc<KB>& A, int off_l, float r_l, int nvalid,
+                                                     const float* __restrict__ Fc, int q) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (!FULL && 32 * g >= nvalid) break;
+        int off_t[8];
+        float r_t[8];
+        float f[8][KB];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            off_t[j] = bperm_i(off_l, 32 * g + 8 * q + j);
+            r_t[j] = bperm_f(r_l, 32 * g + 8 * q + j);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) load_frow<KB>(Fc + (uint32_t)off_t[j], f[j]);
+        i32x4 H[KB], M[KB], L[KB];
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const float x0 = f[j][b], x1 = f[j + 1][b];
+                A.rhs[b] = fmaf(x0, r_t[j], A.rhs[b]);
+                A.rhs[b] = fmaf(x1, r_t[j + 1], A.rhs[b]);
+                A.cs[b] += x0 + x1;
+                const float h0 = __int_as_float(__float_as_int(x0) & 0xFFFF0000);
+                const float h1 = __int_as_float(__float_as_int(x1) & 0xFFFF0000);
+                const float r0 = x0 - h0, r1 = x1 - h1;                       // exact
+                const float m0 = __int_as_float(__float_as_int(r0) & 0xFFFF0000);
+                const float m1 = __int_as_float(__float_as_int(r1) & 0xFFFF0000);
+                const float l0 = r0 - m0, l1 = r1 - m1;                       // exact, <= 8 significant bits
+                H[b][j >> 1] = pack_hi16(x1, x0);
+                M[b][j >> 1] = pack_hi16(r1, r0);
+                L[b][j >> 1] = pack_hi16(l1, l0);
+            }
+        }
+#pragma unroll
+        for (int bi = 0; bi < KB; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) {
+                f32x4 acc = A.acc[blk_idx(bi, bj)];
+                const bf16x8 hi = __builtin_bit_cast(bf16x8, H[bi]), hj = __builtin_bit_cast(bf16x8, H[bj]);
+                const bf16x8 mi = __builtin_bit_cast(bf16x8, M[bi]), mj = __builtin_bit_cast(bf16x8, M[bj]);
+                const bf16x8 li = __builtin_bit_cast(bf16x8, L[bi]), lj = __builtin_bit_cast(bf16x8, L[bj]);
+                // smallest terms first
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(li, hj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, lj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mi, mj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mi, hj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, mj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, hj, acc, 0, 0, 0);
+                A.acc[blk_idx(bi, bj)] = acc;
+            }
+    }
+}
+
+// Long rows in bf16x3 mode: the bf16 MFMA's internal accumulation error grows linearly with the
+// number of accumulated groups (measured 1e-5 relative at 4000 ratings vs 3e-6 for f32 MFMA), so
+// every FLUSH_GROUPS*32 ratings the accumulators are added (fp32, round-to-nearest) into totals
+// kept in the wave's LDS region - idle during the Gram phase and exactly NACC*256 floats - and
+// restarted from zero.
+constexpr int FLUSH_GROUPS = 16;
+
 template <int KB>
+__device__ __forceinline__ void flush_acc(RowAcc<KB>& A, float* __restrict__ Ls, int lane, bool first) {
+#pragma unroll
+    for (int a = 0; a < KCfg<KB>::NACC; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = (a * 4 + r) * 64 + lane;
+            Ls[i] = first ? A.acc[a][r] : Ls[i] + A.acc[a][r];
+            A.acc[a][r] = 0.f;
+        }
+}
+
+template <int KB>
+__device__ __forceinline__ void unflush_acc(RowAcc<KB>& A, const float* __restrict__ Ls, int lane) {
+#pragma unroll
+    for (int a = 0; a < KCfg<KB>::NACC; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A.acc[a][r] += Ls[(a * 4 + r) * 64 + lane];
+}
+
+template <int KB, int MODE>
 __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __restrict__ idxp,
                                                 const float* __restrict__ valp, int len,
                                                 const float* __restrict__ F, int ld, int zero_row,
                                                 const float* __restrict__ bias_other, float mu,
-                                                float bself, int lane) {
+                                                float bself, int lane, float* __restrict__ Ls) {
     const int c = lane & 15, q = lane >> 4;
     const float* Fc = F + KB * c;
+    int nflush = 0;
     // software pipeline over 64-rating chunks: indices two chunks ahead,
     // value + opposite-side bias one chunk ahead of the factor-row gathers
     int idx1 = (lane < len) ? idxp[lane] : zero_row;
@@ -118,8 +220,21 @@ __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __
         A.sumr2 = ok ? fmaf(rb, rb, A.sumr2) : A.sumr2;
         const float r0 = ok ? (rb - bself) : 0.f;
         const int off0 = idx0 * ld;                       // < 2^31 elements (checked by the launcher)
-        if (nvalid == 64) process_chunk<KB, true>(A, off0, r0, 64, Fc, q);
-        else              process_chunk<KB, false>(A, off0, r0, nvalid, Fc, q);
+        if constexpr (MODE == 0) {
+            if (nvalid == 64) process_chunk<KB, true>(A, off0, r0, 64, Fc, q);
+            else              process_chunk<KB, false>(A, off0, r0, nvalid, Fc, q);
+        } else {
+            if (nvalid == 64) process_chunk_bf16x3<KB, true>(A, off0, r0, 64, Fc, q);
+            else              process_chunk_bf16x3<KB, false>(A, off0, r0, nvalid, Fc, q);
+            if (((base >> 6) + 1) % (FLUSH_GROUPS / 2) == 0 && base + 64 < len) {
+                flush_acc<KB>(A, Ls, lane, nflush == 0);
+                ++nflush;
+            }
+        }
+    }
+    if (MODE != 0 && nflush > 0) {
+        unflush_acc<KB>(A, Ls, lane);
+        wave_lds_sync();
     }
 }
 
@@ -478,7 +593,7 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
     }
 }
 
-template <int KB>
+template <int KB, int MODE>
 __global__ __launch_bounds__(64 * KCfg<KB>::WPW, KCfg<KB>::MINW)
 void k_row_tasks(const als_row_solve_params P) {
     using C = KCfg<KB>;
@@ -503,8 +618,8 @@ void k_row_tasks(const als_row_solve_params P) {
     RowAcc<KB> A;
     A.zero();
     if (!(P.reserved0 & 1))        // reserved0: ablation flags for profiling builds, 0 in production
-        gram_accumulate<KB>(A, P.indices + beg, P.vals + beg, len, P.F, P.ld, P.F_zero_row, P.bias_other,
-                            mu, bself, lane);
+        gram_accumulate<KB, MODE>(A, P.indices + beg, P.vals + beg, len, P.F, P.ld, P.F_zero_row,
+                                  P.bias_other, mu, bself, lane, lds_all + wave * C::LDS_FLOATS);
     if (slot >= 0) {
         store_partial<KB>(A, (float*)P.workspace + (size_t)slot * C::SLOT_ITEMS * 64, lane);
         return;
@@ -534,7 +649,10 @@ int launch_row_solve(const als_row_solve_params* p, hipStream_t st) {
     using C = KCfg<KB>;
     if (p->ntasks > 0) {
         const unsigned grid = (unsigned)((p->ntasks + C::WPW - 1) / C::WPW);
-        hipLaunchKernelGGL(k_row_tasks<KB>, dim3(grid), dim3(64 * C::WPW), 0, st, *p);
+        if (p->gram_mode == ALS_GRAM_BF16X3)
+            hipLaunchKernelGGL((k_row_tasks<KB, 1>), dim3(grid), dim3(64 * C::WPW), 0, st, *p);
+        else
+            hipLaunchKernelGGL((k_row_tasks<KB, 0>), dim3(grid), dim3(64 * C::WPW), 0, st, *p);
     }
     if (p->nlong > 0) {
         const unsigned grid = (unsigned)((p->nlong + C::WPW - 1) / C::WPW);
@@ -566,6 +684,7 @@ extern "C" int als_row_solve(const als_row_solve_params* p, void* stream) {
     if (ld < 0) return ALS_E_BADK;
     if (p->ld != ld || !p->indptr || !p->indices || !p->vals || !p->F || !p->bias_self ||
         !p->bias_other || !p->mu || !p->status || p->ntasks < 0 || p->nlong < 0 || p->F_zero_row < 0 ||
+        (p->gram_mode != ALS_GRAM_F32 && p->gram_mode != ALS_GRAM_BF16X3) ||
         (int64_t)p->F_zero_row * ld >= ((int64_t)1 << 31))
         return ALS_E_BADARG;
     if (p->ntasks > 0 && !p->tasks) return ALS_E_BADARG;

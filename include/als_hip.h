@@ -39,6 +39,9 @@ extern "C" {
 #define ALS_E_BADK     (-2)   /* k outside 1..ALS_MAX_K */
 #define ALS_E_LAUNCH   (-3)   /* hipGetLastError() != hipSuccess after a launch */
 
+#define ALS_GRAM_F32    0
+#define ALS_GRAM_BF16X3 1
+
 #define ALS_MAX_K 160
 #define ALS_SPLIT_CHUNK 4096  /* ratings per task segment (see als_task) */
 
@@ -110,7 +113,12 @@ typedef struct als_row_solve_params {
     int32_t F_zero_row;         /* index of an all-zero row of F (ratings past the end of a
                                    row are pointed at it instead of being masked); F_zero_row*ld
                                    and every indices[t]*ld must be < 2^31 */
-    int32_t reserved0;
+    int32_t reserved0;          /* 0 (profiling builds: phase-ablation flags) */
+    int32_t gram_mode;          /* ALS_GRAM_F32: v_mfma_f32_16x16x4_f32 on the gathered floats;
+                                   ALS_GRAM_BF16X3: exact 3-way bf16 split of every float, six cross
+                                   products on v_mfma_f32_16x16x32_bf16, fp32 accumulate (same accuracy
+                                   class, the matrix cores run beside the VALU) */
+    int32_t reserved1;
     const int64_t* indptr;
     const int32_t* indices;
     const float*   vals;

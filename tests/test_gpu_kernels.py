@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _env():
+def _env(gram="bf16x3"):
     import torch
     if not torch.cuda.is_available():
         pytest.fail("GPU tests selected (-m gpu) but no ROCm device is visible")
@@ -15,7 +15,7 @@ def _env():
     from collaborative_filtering_amd.als import _side_to_dev, _tasks_to_dev
     from collaborative_filtering_amd.backend import HipBackend
     dev = torch.device("cuda", 0)
-    return torch, layout, _side_to_dev, _tasks_to_dev, HipBackend(dev), dev
+    return torch, layout, _side_to_dev, _tasks_to_dev, HipBackend(dev, gram=gram), dev
 
 
 def _random_side(layout, nrows, ncols, lens, seed):
@@ -34,9 +34,10 @@ def _pad(A, ld, extra_rows=0):
     return out
 
 
+@pytest.mark.parametrize("gram", ["bf16x3", "f32"])
 @pytest.mark.parametrize("k", [1, 16, 32, 50, 64, 128])
-def test_row_solve_against_numpy(k):
-    torch, layout, side_dev, tasks_dev, be, dev = _env()
+def test_row_solve_against_numpy(k, gram):
+    torch, layout, side_dev, tasks_dev, be, dev = _env(gram)
     ncols = 9000
     lens = [1, 2, 0, k // 2 + 1, k, 3 * k + 5, 700, 0, 4096, 4097, 8200 + k, 33, 64, 65, 5]
     nrows = len(lens)

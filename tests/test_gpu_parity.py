@@ -43,12 +43,15 @@ def _close(got, ref, rtol=2e-3, atol_rel=2e-4, what=""):
     np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol, err_msg=what)
 
 
+@pytest.mark.parametrize("gram", ["bf16x3", "f32"])
 @pytest.mark.parametrize("name", golden_names())
-def test_fit_matches_reference_fixture(name):
+def test_fit_matches_reference_fixture(name, gram):
+    """Both Gram modes of K1 (f32 MFMA; exact 3-way bf16 split on the bf16 matrix cores) are held
+    to the same tolerances against the float64 reference."""
     _cuda()
     g = Golden(name)
     d = g.d
-    model = _model_for(g)
+    model = _model_for(g, gram=gram)
     r, c, v = g.train
     model.fit_coo(r, c, v, (g.m, g.n), features=g.features or None, tol=g.cfg["tol"],
                   min_iters=g.cfg["min_iters"], verbose=0)
