@@ -344,6 +344,14 @@ class _Engine:
                 sched = layout.build_level_schedule(ptr, idx, active, 0, self.n)
             self.sched = sched
             self.sched_items = torch.from_numpy(sched.items).to(device)
+            # persistent dataflow sweep (one launch, no level barriers) when the backend has it
+            self.gs_dataflow = (hasattr(backend, "gs_dataflow") and self.ld <= 64
+                                and not (self.world > 1 and self.gs_mode == "exact"))
+            if self.gs_dataflow:
+                self.S_idx_wait = torch.from_numpy(layout.wait_edges(ptr, idx, sched.level)).to(device)
+                self.gs_done = torch.zeros(n_pad, dtype=torch.int32, device=device)
+                self.gs_err = torch.zeros(1, dtype=torch.int32, device=device)
+                self.gs_sweeps = 0
             self.factor = torch.zeros(n_pad * self.ld * self.ld, dtype=f32, device=device)
             self.sumr = torch.zeros(n_pad, dtype=f32, device=device)
         need_byproducts = self.use_graph or bool(self.feat_names)
@@ -392,6 +400,8 @@ class _Engine:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
 
     def _check_status(self):
+        if getattr(self, "gs_dataflow", False) and int(self.gs_err.item()):
+            raise RuntimeError("Gauss-Seidel dataflow sweep: a dependency wait timed out")
         bad = int(self.status.item())
         if bad:
             self.status.zero_()
@@ -471,6 +481,11 @@ class _Engine:
                   V=self.V, bias=self.b_i)
         if self.fused_stats:
             kw.update(sumr2=self.sumr2, lambda_eff=self.lam_eff, stat_out=self.stat_rows)
+        if self.gs_dataflow:
+            self.gs_sweeps += 1
+            self.be.gs_dataflow(items=self.sched_items, S_idx_wait=self.S_idx_wait, done=self.gs_done,
+                                sweep_id=self.gs_sweeps, err=self.gs_err, **kw)
+            return
         if not exact_multi and hasattr(self.be, "gs_levels"):
             # no collective between levels: the whole sweep is one C call (one launch per level)
             self.be.gs_levels(offsets=np.ascontiguousarray(off, dtype=np.int64), items=self.sched_items, **kw)

@@ -85,6 +85,23 @@ class HipBackend:
         p.V, p.bias = _p(V), _p(bias)
         self._check(self.lib.als_gs_sweep(C.byref(p), self._stream()), "als_gs_sweep")
 
+    def _gs_params(self, items, kw):
+        p = _hip.GsSweepParams()
+        p.k, p.ld = kw["k"], kw["ld"]
+        p.items, p.nitems = _p(items), items.numel()
+        p.S_ptr, p.S_idx, p.S_val, p.alpha = _p(kw["S_ptr"]), _p(kw["S_idx"]), _p(kw["S_val"]), float(kw["alpha"])
+        p.factor, p.rhs, p.colsum, p.sumr = _p(kw["factor"]), _p(kw["rhs"]), _p(kw["colsum"]), _p(kw["sumr"])
+        p.indptr, p.lambda_bias_scalar, p.lambda_bias_row = _p(kw["indptr"]), float(kw["lam_b"]), _p(kw["lam_b_row"])
+        p.V, p.bias = _p(kw["V"]), _p(kw["bias"])
+        p.sumr2, p.lambda_eff, p.stat_out = _p(kw.get("sumr2")), _p(kw.get("lambda_eff")), _p(kw.get("stat_out"))
+        return p
+
+    def gs_dataflow(self, *, items, S_idx_wait, done, sweep_id, err, **kw):
+        """Whole sweep as one persistent launch (k <= 64); see als_gs_sweep_dataflow."""
+        p = self._gs_params(items, kw)
+        self._check(self.lib.als_gs_sweep_dataflow(C.byref(p), _p(S_idx_wait), _p(done), int(sweep_id), _p(err),
+                                                   self._stream()), "als_gs_sweep_dataflow")
+
     def gs_levels(self, *, offsets, **kw):
         """All levels of the sweep with one C call (offsets: host int64 numpy array, nlevels+1)."""
         items = kw.pop("items")

@@ -149,6 +149,134 @@ void k_gs_level(const als_gs_sweep_params P) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// K2': the whole sweep as ONE persistent, synchronisation-free launch (k <= 64).
+//
+// Items are listed in (level, id) order and dealt round-robin to `nwaves` co-resident waves
+// (one workgroup per CU); each wave walks its items in that order.  An item waits only for the
+// neighbours it really depends on (j < i and swept - flagged by the sign bit of `Sw`), by polling
+// their done-flags; there is no level barrier.  Progress: the earliest unfinished item in the
+// global order has all dependencies finished and is the next item of a resident wave.
+//
+// Cross-CU / cross-XCD visibility follows cdna_hip_programming.md Guideline 16, form R1: every
+// store of a handed-off V row and of its flag is an agent-scope (sc1, write-through) store, the
+// storing wave drains them (s_waitcnt vmcnt(0)) before the flag, and EVERY load of V rows and
+// flags in this kernel is an agent-scope (sc1, L1-bypassing) load.  Flags hold the sweep number,
+// so they never need resetting.  Every spin is bounded: on timeout the wave raises `err` and
+// carries on with whatever it read (wrong numbers, no hang) - the host turns it into an error.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float ld_agent(const float* p) {
+    return __int_as_float(__hip_atomic_load(reinterpret_cast<const int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<int*>(p), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int KB>
+__global__ __launch_bounds__(256)
+void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, int32_t* done, int sweep_id,
+                   int32_t* err, int64_t nitems, int nwaves) {
+    using C = KCfg<KB>;
+    constexpr int KP = C::KP;
+    static_assert(KB <= 4, "dataflow sweep: k <= 64");
+    constexpr unsigned long long SPIN_LIMIT = 1ull << 28;      // ~0.12 s of shader clock
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = min(lane, KP - 1);
+    const int col = perm_to_col<KB>(i);
+    for (int64_t it = gw; it < nitems; it += nwaves) {
+        const int item = P.items[it];
+        const int64_t i64 = item;
+        const int64_t s0 = P.S_ptr[item], s1 = P.S_ptr[item + 1];
+        const float nnz = (float)(P.indptr[item + 1] - P.indptr[item]);
+        const float lb = P.lambda_bias_row ? P.lambda_bias_row[item] : P.lambda_bias_scalar;
+        const float* M = P.factor + i64 * KP * KP;
+        // factor column, rhs, column sums: written by an earlier launch, plain loads, requested first
+        float a[KP];
+#pragma unroll
+        for (int p = 0; p < KP; ++p) a[p] = M[p * KP + i];
+        const float di = M[i * KP + i];
+        const float rhs_i = P.rhs[i64 * KP + i];
+        const float cs_i = P.colsum[i64 * KP + i];
+        float g = 0.f;
+        for (int64_t t0 = s0; t0 < s1; t0 += 64) {
+            const int nn = (int)min((int64_t)64, s1 - t0);
+            const int raw = (lane < nn) ? Sw[t0 + lane] : item;
+            const int sj_l = raw & 0x7fffffff;
+            const float sv_l = (lane < nn) ? P.S_val[t0 + lane] : 0.f;
+            // dependencies of this chunk (a timeout anywhere is sticky: nobody waits after it)
+            if (__any(raw < 0) && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                const unsigned long long tstart = __builtin_amdgcn_s_memtime();
+                bool ok = (raw >= 0) || (__hip_atomic_load(done + sj_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sweep_id);
+                while (!__all(ok)) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (!ok) ok = __hip_atomic_load(done + sj_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sweep_id;
+                    if (__builtin_amdgcn_s_memtime() - tstart > SPIN_LIMIT ||
+                        __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        if (lane == 0) atomicExch(err, 1);
+                        break;
+                    }
+                }
+            }
+            for (int e0 = 0; e0 < nn; e0 += 16) {
+                float vv[16], sv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int sj = __shfl(sj_l, e0 + e, 64);          // lanes >= nn carry (item, 0)
+                    sv[e] = __shfl(sv_l, e0 + e, 64);
+                    vv[e] = ld_agent(P.V + (int64_t)sj * P.ld + col);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) g = fmaf(sv[e], vv[e], g);
+            }
+        }
+        const float rb = rhs_i + P.alpha * g;
+        float y = 0.f;
+        const float x = solve_regs<KP>(a, di, rb, lane, &y);
+        float dot = 0.f, xr = 0.f, yy = 0.f, xx = 0.f;
+        if (lane < KP) {
+            st_agent(P.V + i64 * P.ld + col, x);
+            dot = cs_i * x; xr = rhs_i * x; yy = y * y; xx = x * x;
+        }
+        dot = wave_sum(dot);
+        const float sumr = P.sumr[item];
+        const float bnew = (sumr - dot) / (nnz + lb + ALS_EPS);
+        const float bold = P.bias[item];
+        __builtin_amdgcn_sched_barrier(0);
+        if (lane == 0) P.bias[item] = bnew;
+        if (P.stat_out) {
+            xr = wave_sum(xr); yy = wave_sum(yy); xx = wave_sum(xx);
+            if (lane == 0) {
+                const float sumr2 = P.sumr2[item];
+                const float s1v = sumr - nnz * bnew;
+                const float s2v = sumr2 - 2.f * bnew * sumr + nnz * bnew * bnew;
+                const float cross = xr + (bold - bnew) * dot;
+                const float quad = yy - P.lambda_eff[item] * xx;
+                P.stat_out[2 * i64] = s1v - dot;
+                P.stat_out[2 * i64 + 1] = s2v - 2.f * cross + quad;
+            }
+        }
+        // publish: every store of the row has left the wave before the flag does
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(done + item, sweep_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int KB>
+int launch_gs_dataflow(const als_gs_sweep_params* p, const int32_t* Sw, int32_t* done, int sweep_id,
+                       int32_t* err, int64_t nitems, hipStream_t st) {
+    if constexpr (KB <= 4) {
+        // one 4-wave workgroup per CU: 1024 waves are always co-resident on the 256-CU part
+        int nwg = 256;
+        if ((int64_t)nwg * 4 > nitems) nwg = (int)((nitems + 3) / 4);
+        if (nwg < 1) return 0;
+        hipLaunchKernelGGL(k_gs_dataflow<KB>, dim3(nwg), dim3(256), 0, st, *p, Sw, done, sweep_id, err, nitems, nwg * 4);
+        return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
+    } else {
+        return ALS_E_BADK;
+    }
+}
+
 template <int KB>
 int launch_gs(const als_gs_sweep_params* p, hipStream_t st) {
     constexpr int WPW = GsCfg<KB>::WPW;
@@ -159,6 +287,26 @@ int launch_gs(const als_gs_sweep_params* p, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t* S_idx_wait, int32_t* done,
+                                     int32_t sweep_id, int32_t* err, void* stream) {
+    if (!p || !S_idx_wait || !done || !err || sweep_id <= 0) return ALS_E_BADARG;
+    const int ld = als_padded_k(p->k);
+    if (ld < 0) return ALS_E_BADK;
+    if (ld > 64) return ALS_E_BADK;
+    if (p->ld != ld || p->nitems < 0 || !p->S_ptr || !p->S_val || !p->factor || !p->rhs || !p->colsum ||
+        !p->sumr || !p->indptr || !p->V || !p->bias || (p->nitems > 0 && !p->items))
+        return ALS_E_BADARG;
+    if (p->stat_out && (!p->sumr2 || !p->lambda_eff)) return ALS_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (ld / 16) {
+        case 1: return launch_gs_dataflow<1>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
+        case 2: return launch_gs_dataflow<2>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
+        case 3: return launch_gs_dataflow<3>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
+        case 4: return launch_gs_dataflow<4>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
+    }
+    return ALS_E_BADK;
+}
 
 extern "C" int als_gs_sweep_levels(const als_gs_sweep_params* p, const int64_t* level_offsets,
                                    int64_t nlevels, void* stream) {

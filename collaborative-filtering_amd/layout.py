@@ -162,6 +162,19 @@ def dense_graph_to_csr(S: np.ndarray):
 class LevelSchedule:
     items: np.ndarray        # int32: swept items, grouped by level, ascending id inside
     offsets: np.ndarray      # int64 [nlevels+1] into items
+    level: np.ndarray        # int64 [n]: level of every item, -1 if it is not swept
+
+
+def wait_edges(S_ptr: np.ndarray, S_idx: np.ndarray, level: np.ndarray) -> np.ndarray:
+    """S_idx with the sign bit set on the edges (i -> j) the sweep of item i must wait for:
+    j < i and j swept (level[j] >= 0).  Input of als_gs_sweep_dataflow."""
+    n = len(S_ptr) - 1
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(S_ptr))
+    j = S_idx.astype(np.int64)
+    wait = (j < rows) & (level[j] >= 0) & (level[rows] >= 0)
+    out = S_idx.astype(np.int32).copy()
+    out[wait] |= np.int32(-2147483648)
+    return out
 
 
 def build_level_schedule(S_ptr: np.ndarray, S_idx: np.ndarray, active: np.ndarray,
@@ -191,4 +204,4 @@ def build_level_schedule(S_ptr: np.ndarray, S_idx: np.ndarray, active: np.ndarra
     offsets = np.zeros(nlev + 1, dtype=np.int64)
     if swept.size:
         np.cumsum(np.bincount(level[swept], minlength=nlev), out=offsets[1:])
-    return LevelSchedule(items, offsets)
+    return LevelSchedule(items, offsets, level)
