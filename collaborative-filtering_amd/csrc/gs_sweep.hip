@@ -204,30 +204,60 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
             const int raw = (lane < nn) ? Sw[t0 + lane] : item;
             const int sj_l = raw & 0x7fffffff;
             const float sv_l = (lane < nn) ? P.S_val[t0 + lane] : 0.f;
-            // dependencies of this chunk (a timeout anywhere is sticky: nobody waits after it)
-            if (__any(raw < 0) && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                const unsigned long long tstart = __builtin_amdgcn_s_memtime();
-                bool ok = (raw >= 0) || (__hip_atomic_load(done + sj_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sweep_id);
-                while (!__all(ok)) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (!ok) ok = __hip_atomic_load(done + sj_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sweep_id;
-                    if (__builtin_amdgcn_s_memtime() - tstart > SPIN_LIMIT ||
-                        __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        if (lane == 0) atomicExch(err, 1);
-                        break;
-                    }
-                }
-            }
+            // Pass 1: one look at the flags; every neighbour that is not a dependency, or whose
+            // dependency is already met, is gathered now (weight 0 for the rest) - typically all
+            // but the few rows of the immediately preceding levels.
+            const bool need = raw < 0;
+            bool ok = !need || (__hip_atomic_load(done + sj_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sweep_id);
+            const float sv_now = ok ? sv_l : 0.f;
             for (int e0 = 0; e0 < nn; e0 += 16) {
                 float vv[16], sv[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int sj = __shfl(sj_l, e0 + e, 64);          // lanes >= nn carry (item, 0)
-                    sv[e] = __shfl(sv_l, e0 + e, 64);
+                    sv[e] = __shfl(sv_now, e0 + e, 64);
                     vv[e] = ld_agent(P.V + (int64_t)sj * P.ld + col);
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) g = fmaf(sv[e], vv[e], g);
+            }
+            // Pass 2: the outstanding dependencies, fetched as they complete (a timeout anywhere is
+            // sticky: nobody waits after it)
+            unsigned long long pend = __ballot(!ok);
+            if (pend) {
+                const unsigned long long tstart = __builtin_amdgcn_s_memtime();
+                bool bail = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                while (pend) {
+                    if (!ok) ok = bail || (__hip_atomic_load(done + sj_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sweep_id);
+                    unsigned long long rdy = __ballot(ok) & pend;
+                    pend &= ~rdy;
+                    while (rdy) {                       // up to 4 freshly completed rows per round trip
+                        int e[4];
+                        float w[4], v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            e[u] = rdy ? (int)__builtin_ctzll(rdy) : -1;
+                            if (rdy) rdy &= rdy - 1;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int src = e[u] < 0 ? 0 : e[u];
+                            const int sj = __shfl(sj_l, src, 64);
+                            w[u] = e[u] < 0 ? 0.f : __shfl(sv_l, src, 64);
+                            v[u] = ld_agent(P.V + (int64_t)sj * P.ld + col);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) g = fmaf(w[u], v[u], g);
+                    }
+                    if (pend) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (__builtin_amdgcn_s_memtime() - tstart > SPIN_LIMIT ||
+                            __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                            if (lane == 0) atomicExch(err, 1);
+                            bail = true;
+                        }
+                    }
+                }
             }
         }
         const float rb = rhs_i + P.alpha * g;
