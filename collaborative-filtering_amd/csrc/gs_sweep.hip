@@ -263,11 +263,13 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
         const float rb = rhs_i + P.alpha * g;
         float y = 0.f;
         const float x = solve_regs<KP>(a, di, rb, lane, &y);
+        // publish first: every store of the row has left the wave before the flag does; the bias
+        // and the statistics below are nobody's dependency
+        if (lane < KP) st_agent(P.V + i64 * P.ld + col, x);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(done + item, sweep_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         float dot = 0.f, xr = 0.f, yy = 0.f, xx = 0.f;
-        if (lane < KP) {
-            st_agent(P.V + i64 * P.ld + col, x);
-            dot = cs_i * x; xr = rhs_i * x; yy = y * y; xx = x * x;
-        }
+        if (lane < KP) { dot = cs_i * x; xr = rhs_i * x; yy = y * y; xx = x * x; }
         dot = wave_sum(dot);
         const float sumr = P.sumr[item];
         const float bnew = (sumr - dot) / (nnz + lb + ALS_EPS);
@@ -286,9 +288,6 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
                 P.stat_out[2 * i64 + 1] = s2v - 2.f * cross + quad;
             }
         }
-        // publish: every store of the row has left the wave before the flag does
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(done + item, sweep_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
