@@ -37,9 +37,12 @@ if ROOT not in sys.path:
 GENRE_RATES = [0.1869, 0.1307, 0.0516, 0.0719, 0.3847, 0.1217, 0.0394, 0.4524, 0.0779, 0.01,
                0.099, 0.0133, 0.0378, 0.0568, 0.1749, 0.0956, 0.199, 0.0408, 0.0177]
 
-SIZES = {   # name: (m, n, nnz, k)
+SIZES = {   # name: (m, n, nnz, k)   - cfg4 is the headline; the others are diagnostics
+    "cfg2": (6_040, 3_706, 1_000_000, 32),                # BASELINE configs[1]: +bias, no graph
+    "cfg3": (138_493, 26_744, 20_000_000, 64),            # BASELINE configs[2]: +W_f (genres, years), no graph
     "cfg4": (1_000_000, 100_000, 100_000_000, 64),
     "cfg4-small": (100_000, 10_000, 5_000_000, 64),       # rehearsal size
+    "cfg5-small": (200_000, 20_000, 10_000_000, 128),     # BASELINE configs[4] shape / 50: full model, k = 128
     "tiny": (4_000, 1_500, 150_000, 64),
 }
 
@@ -124,6 +127,15 @@ def gen_graph(dev, n, seed, topk=50, ncand=512):
     ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     ptr[1:] = torch.cumsum(torch.bincount(sr, minlength=n), 0)
     return ptr, sc.to(torch.int32), sv.to(torch.float32)
+
+
+def gen_features(n, seed):
+    """genres: n x 19 Bernoulli at the shipped file's column rates, row-L2; years: n x 1 z-scored."""
+    rng = np.random.default_rng(seed)
+    G = (rng.random((n, 19)) < np.asarray(GENRE_RATES)[None, :]).astype(np.float64)
+    G = (G / np.maximum(np.sqrt((G * G).sum(1, keepdims=True)), 1e-8)).astype(np.float32)
+    y = rng.normal(size=(n, 1))
+    return {"genres": G, "years": ((y - y.mean()) / y.std()).astype(np.float32)}
 
 
 def cpu_baseline(eng, budget_s=20.0):
@@ -231,9 +243,11 @@ def main():
     m, n, nnz, k = SIZES[args.size]
     t_setup = time.perf_counter()
     # rank 0 generates, everybody receives the same bytes (robust against RNG differences)
+    use_graph = (not args.no_graph) and args.size not in ("cfg2", "cfg3")
+    features = gen_features(n, 3004) if args.size in ("cfg3", "cfg5-small") else None
     if rank == 0:
         csr, csc = gen_ratings(dev, m, n, nnz, seed=1004)
-        S = None if args.no_graph else gen_graph(dev, n, seed=2004)
+        S = gen_graph(dev, n, seed=2004) if use_graph else None
     if world > 1:
         def bc(t, dtype, numel):
             if rank != 0:
@@ -248,7 +262,7 @@ def main():
                     enumerate([(torch.int64, m + 1), (torch.int32, N), (torch.float32, N)]))
         csc = tuple(bc(csc[j] if rank == 0 else None, dt, sz) for j, (dt, sz) in
                     enumerate([(torch.int64, n + 1), (torch.int32, N), (torch.float32, N)]))
-        if not args.no_graph:
+        if use_graph:
             S = tuple(bc(S[j] if rank == 0 else None, dt, sz) for j, (dt, sz) in
                       enumerate([(torch.int64, n + 1), (torch.int32, NS), (torch.float32, NS)]))
         else:
@@ -256,12 +270,16 @@ def main():
     nnz = int(csr[1].numel())
 
     n_total = args.warmup + args.steps
-    cfg = ALSConfig(core=CoreConfig(n_factors=k, n_iters=n_total, lambda_u=5.0, lambda_v=6.0, random_state=42),
+    cfg = ALSConfig(core=CoreConfig(n_factors=k, n_iters=n_total, lambda_u=5.0, lambda_v=6.0, random_state=42,
+                                    pop_reg_mode="inverse_sqrt" if args.size == "cfg5-small" else None),
                     biases=BiasesConfig(lambda_bu=3.0, lambda_bi=2.0),
                     graph=(GraphConfig(alpha=0.5, sim=GraphSimConfig(source="precomputed", topk=50))
                            if S is not None else GraphConfig()))
-    model = ALS(cfg, device=dev, gs_mode=args.gs_mode, gram=args.gram)
-    eng = model.prepare_csr(csr, csc, (m, n), S=S)
+    model = ALS(cfg, lambda_w={"genres": 5.0, "years": 10.0} if features else None,
+                device=dev, gs_mode=args.gs_mode, gram=args.gram)
+    eng = model.prepare_csr(csr, csc, (m, n), features=features, S=S)
+    if features:
+        eng.be.compose_z(eng.V, eng.Xcat, eng.Wcat, eng.Z)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 

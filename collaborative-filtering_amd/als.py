@@ -345,7 +345,7 @@ class _Engine:
             self.sched = sched
             self.sched_items = torch.from_numpy(sched.items).to(device)
             # persistent dataflow sweep (one launch, no level barriers) when the backend has it
-            self.gs_dataflow = (hasattr(backend, "gs_dataflow") and self.ld <= 64
+            self.gs_dataflow = (hasattr(backend, "gs_dataflow")
                                 and not (self.world > 1 and self.gs_mode == "exact"))
             if self.gs_dataflow:
                 self.S_idx_wait = torch.from_numpy(layout.wait_edges(ptr, idx, sched.level)).to(device)
@@ -362,7 +362,8 @@ class _Engine:
 
         # --- fused statistics (DESIGN.md "Statistics"): without features Z == V, so the residual
         #     sums of an iteration follow in closed form from what the V-step already holds
-        self.fused_stats = (not self.feat_names) and self.ld <= 64 and hasattr(backend, "sum_pairs")
+        self.fused_stats = ((not self.feat_names) and hasattr(backend, "sum_pairs")
+                            and (self.ld <= 64 or not self.use_graph or getattr(self, "gs_dataflow", False)))
         if self.fused_stats:
             self.stat_rows = torch.zeros(n_pad, 2, dtype=f32, device=device)
             if self.use_graph:
@@ -615,7 +616,8 @@ class _Engine:
         b_i_old = self.b_i.clone() if do_w else None
         self.item_step(want_gram=do_w)
         if do_w:
-            self.w_step(b_i_old)
+            with self._tick("w_step"):
+                self.w_step(b_i_old)
         self.stats_step(it)
         self.iters_run = it + 1
 

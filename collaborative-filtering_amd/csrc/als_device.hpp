@@ -119,6 +119,93 @@ __device__ __forceinline__ float solve_regs(const float (&a)[KP], float di, floa
     return rs;
 }
 
+// any KP, coefficients streamed from the factor image in global memory (the symmetric completion
+// M of L written by als_row_solve: M[p][i] = L[i][p] for p < i, L[p][i] for p > i, 1/L[i][i] on
+// the diagonal).  Lane (+64 rr) owns unknown i = lane + 64 rr and needs exactly column i of M,
+// i.e. M[p*KP + i] - coalesced across lanes for every p.  16 steps are loaded at a time, the next
+// block is requested before the current one is consumed, so registers stay at 2*16*NR for any k.
+// rb enters as b, leaves as x; y_out (optional) receives the forward-solved vector.
+template <int KB>
+__device__ __forceinline__ void solve_stream(const float* __restrict__ M, float (&rb)[KCfg<KB>::NR], int lane,
+                                             float* y_out = nullptr) {
+    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR;
+    int ic[NR];
+    float di[NR], rs[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        ic[rr] = min(lane + 64 * rr, KP - 1);
+        di[rr] = M[ic[rr] * KP + ic[rr]];
+        rs[rr] = rb[rr] * di[rr];
+    }
+    float cur[NR][16], nxt[NR][16];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) cur[rr][t] = M[t * KP + ic[rr]];
+    // L y = b, blocks ascending
+#pragma unroll
+    for (int pb = 0; pb < KB; ++pb) {
+        if (pb + 1 < KB) {
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) nxt[rr][t] = M[(16 * (pb + 1) + t) * KP + ic[rr]];
+        } else {    // first block of the transposed sweep
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) nxt[rr][t] = M[(16 * (KB - 1) + t) * KP + ic[rr]];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int j = 16 * pb + t;
+            const float yj = readlane_f(rs[j >> 6], j & 63);
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                const float cf = (lane + 64 * rr > j) ? cur[rr][t] * di[rr] : 0.f;
+                rs[rr] = fmaf(-cf, yj, rs[rr]);
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) cur[rr][t] = nxt[rr][t];
+    }
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        if (y_out) y_out[rr] = rs[rr];      // lane holds y_i
+        rs[rr] *= di[rr];
+    }
+    // L^T x = y, blocks descending (cur already holds the last block)
+#pragma unroll
+    for (int pb = KB - 1; pb >= 0; --pb) {
+        if (pb > 0) {
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) nxt[rr][t] = M[(16 * (pb - 1) + t) * KP + ic[rr]];
+        }
+#pragma unroll
+        for (int t = 15; t >= 0; --t) {
+            const int j = 16 * pb + t;
+            const float xj = readlane_f(rs[j >> 6], j & 63);
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                const float cf = (lane + 64 * rr < j) ? cur[rr][t] * di[rr] : 0.f;
+                rs[rr] = fmaf(-cf, xj, rs[rr]);
+            }
+        }
+        if (pb > 0) {
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) cur[rr][t] = nxt[rr][t];
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) rb[rr] = rs[rr];
+}
+
 // any KP, L in LDS: Al[j*LD + i] = L[i][j] (i > j), dinv[j] = 1/L[j][j].
 // vec[] (LDS, perm space) holds b on entry and x on exit.
 template <int KB, int LD>

@@ -177,13 +177,16 @@ __global__ __launch_bounds__(256)
 void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, int32_t* done, int sweep_id,
                    int32_t* err, int64_t nitems, int nwaves) {
     using C = KCfg<KB>;
-    constexpr int KP = C::KP;
-    static_assert(KB <= 4, "dataflow sweep: k <= 64");
+    constexpr int KP = C::KP, NR = C::NR;
     constexpr unsigned long long SPIN_LIMIT = 1ull << 28;      // ~0.12 s of shader clock
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int i = min(lane, KP - 1);
-    const int col = perm_to_col<KB>(i);
+    int ic[NR], col[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        ic[rr] = min(lane + 64 * rr, KP - 1);
+        col[rr] = perm_to_col<KB>(ic[rr]);
+    }
     for (int64_t it = gw; it < nitems; it += nwaves) {
         const int item = P.items[it];
         const int64_t i64 = item;
@@ -191,14 +194,23 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
         const float nnz = (float)(P.indptr[item + 1] - P.indptr[item]);
         const float lb = P.lambda_bias_row ? P.lambda_bias_row[item] : P.lambda_bias_scalar;
         const float* M = P.factor + i64 * KP * KP;
-        // factor column, rhs, column sums: written by an earlier launch, plain loads, requested first
-        float a[KP];
+        // k <= 64: the lane's factor column (written by an earlier launch, plain loads) is requested
+        // first and streams in underneath the waits; k > 64 streams it during the solve
+        constexpr int KPR = (KB <= 4) ? KP : 1;
+        float a[KPR];
+        float di0 = 0.f;
+        if constexpr (KB <= 4) {
 #pragma unroll
-        for (int p = 0; p < KP; ++p) a[p] = M[p * KP + i];
-        const float di = M[i * KP + i];
-        const float rhs_i = P.rhs[i64 * KP + i];
-        const float cs_i = P.colsum[i64 * KP + i];
-        float g = 0.f;
+            for (int p = 0; p < KP; ++p) a[p] = M[p * KP + ic[0]];
+            di0 = M[ic[0] * KP + ic[0]];
+        }
+        float rhs_i[NR], cs_i[NR], g[NR];
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            rhs_i[rr] = P.rhs[i64 * KP + ic[rr]];
+            cs_i[rr] = P.colsum[i64 * KP + ic[rr]];
+            g[rr] = 0.f;
+        }
         for (int64_t t0 = s0; t0 < s1; t0 += 64) {
             const int nn = (int)min((int64_t)64, s1 - t0);
             const int raw = (lane < nn) ? Sw[t0 + lane] : item;
@@ -210,16 +222,20 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
             const bool need = raw < 0;
             bool ok = !need || (__hip_atomic_load(done + sj_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sweep_id);
             const float sv_now = ok ? sv_l : 0.f;
-            for (int e0 = 0; e0 < nn; e0 += 16) {
-                float vv[16], sv[16];
+            constexpr int GB = (NR == 1) ? 16 : 8;
+            for (int e0 = 0; e0 < nn; e0 += GB) {
+                float vv[GB][NR], sv[GB];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int sj = __shfl(sj_l, e0 + e, 64);          // lanes >= nn carry (item, 0)
-                    sv[e] = __shfl(sv_now, e0 + e, 64);
-                    vv[e] = ld_agent(P.V + (int64_t)sj * P.ld + col);
+                for (int e = 0; e < GB; ++e) {
+                    const int sj = __shfl(sj_l, min(e0 + e, 63), 64);   // lanes >= nn carry (item, 0)
+                    sv[e] = (e0 + e < 64) ? __shfl(sv_now, min(e0 + e, 63), 64) : 0.f;
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr) vv[e][rr] = ld_agent(P.V + (int64_t)sj * P.ld + col[rr]);
                 }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) g = fmaf(sv[e], vv[e], g);
+                for (int e = 0; e < GB; ++e)
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr) g[rr] = fmaf(sv[e], vv[e][rr], g[rr]);
             }
             // Pass 2: the outstanding dependencies, fetched as they complete (a timeout anywhere is
             // sticky: nobody waits after it)
@@ -233,7 +249,7 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
                     pend &= ~rdy;
                     while (rdy) {                       // up to 4 freshly completed rows per round trip
                         int e[4];
-                        float w[4], v[4];
+                        float w[4], v[4][NR];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             e[u] = rdy ? (int)__builtin_ctzll(rdy) : -1;
@@ -244,10 +260,13 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
                             const int src = e[u] < 0 ? 0 : e[u];
                             const int sj = __shfl(sj_l, src, 64);
                             w[u] = e[u] < 0 ? 0.f : __shfl(sv_l, src, 64);
-                            v[u] = ld_agent(P.V + (int64_t)sj * P.ld + col);
+#pragma unroll
+                            for (int rr = 0; rr < NR; ++rr) v[u][rr] = ld_agent(P.V + (int64_t)sj * P.ld + col[rr]);
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) g = fmaf(w[u], v[u], g);
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int rr = 0; rr < NR; ++rr) g[rr] = fmaf(w[u], v[u][rr], g[rr]);
                     }
                     if (pend) {
                         __builtin_amdgcn_s_sleep(1);
@@ -260,16 +279,28 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
                 }
             }
         }
-        const float rb = rhs_i + P.alpha * g;
-        float y = 0.f;
-        const float x = solve_regs<KP>(a, di, rb, lane, &y);
+        float x[NR], y[NR];
+        if constexpr (KB <= 4) {
+            x[0] = solve_regs<KP>(a, di0, rhs_i[0] + P.alpha * g[0], lane, &y[0]);
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) x[rr] = rhs_i[rr] + P.alpha * g[rr];
+            solve_stream<KB>(M, x, lane, y);
+        }
         // publish first: every store of the row has left the wave before the flag does; the bias
         // and the statistics below are nobody's dependency
-        if (lane < KP) st_agent(P.V + i64 * P.ld + col, x);
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr)
+            if (lane + 64 * rr < KP) st_agent(P.V + i64 * P.ld + col[rr], x[rr]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(done + item, sweep_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         float dot = 0.f, xr = 0.f, yy = 0.f, xx = 0.f;
-        if (lane < KP) { dot = cs_i * x; xr = rhs_i * x; yy = y * y; xx = x * x; }
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr)
+            if (lane + 64 * rr < KP) {
+                dot = fmaf(cs_i[rr], x[rr], dot); xr = fmaf(rhs_i[rr], x[rr], xr);
+                yy = fmaf(y[rr], y[rr], yy); xx = fmaf(x[rr], x[rr], xx);
+            }
         dot = wave_sum(dot);
         const float sumr = P.sumr[item];
         const float bnew = (sumr - dot) / (nnz + lb + ALS_EPS);
@@ -294,16 +325,12 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
 template <int KB>
 int launch_gs_dataflow(const als_gs_sweep_params* p, const int32_t* Sw, int32_t* done, int sweep_id,
                        int32_t* err, int64_t nitems, hipStream_t st) {
-    if constexpr (KB <= 4) {
-        // one 4-wave workgroup per CU: 1024 waves are always co-resident on the 256-CU part
-        int nwg = 256;
-        if ((int64_t)nwg * 4 > nitems) nwg = (int)((nitems + 3) / 4);
-        if (nwg < 1) return 0;
-        hipLaunchKernelGGL(k_gs_dataflow<KB>, dim3(nwg), dim3(256), 0, st, *p, Sw, done, sweep_id, err, nitems, nwg * 4);
-        return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
-    } else {
-        return ALS_E_BADK;
-    }
+    // one 4-wave workgroup per CU: 1024 waves are always co-resident on the 256-CU part
+    int nwg = 256;
+    if ((int64_t)nwg * 4 > nitems) nwg = (int)((nitems + 3) / 4);
+    if (nwg < 1) return 0;
+    hipLaunchKernelGGL(k_gs_dataflow<KB>, dim3(nwg), dim3(256), 0, st, *p, Sw, done, sweep_id, err, nitems, nwg * 4);
+    return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
 }
 
 template <int KB>
@@ -322,7 +349,6 @@ extern "C" int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t
     if (!p || !S_idx_wait || !done || !err || sweep_id <= 0) return ALS_E_BADARG;
     const int ld = als_padded_k(p->k);
     if (ld < 0) return ALS_E_BADK;
-    if (ld > 64) return ALS_E_BADK;
     if (p->ld != ld || p->nitems < 0 || !p->S_ptr || !p->S_val || !p->factor || !p->rhs || !p->colsum ||
         !p->sumr || !p->indptr || !p->V || !p->bias || (p->nitems > 0 && !p->items))
         return ALS_E_BADARG;
@@ -333,6 +359,12 @@ extern "C" int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t
         case 2: return launch_gs_dataflow<2>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
         case 3: return launch_gs_dataflow<3>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
         case 4: return launch_gs_dataflow<4>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
+        case 5: return launch_gs_dataflow<5>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
+        case 6: return launch_gs_dataflow<6>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
+        case 7: return launch_gs_dataflow<7>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
+        case 8: return launch_gs_dataflow<8>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
+        case 9: return launch_gs_dataflow<9>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
+        case 10: return launch_gs_dataflow<10>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
     }
     return ALS_E_BADK;
 }

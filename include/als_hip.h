@@ -178,7 +178,7 @@ typedef struct als_gs_sweep_params {
 
 int als_gs_sweep(const als_gs_sweep_params* p, void* stream);
 
-/* Whole sweep as ONE persistent launch without level barriers (k <= 64).  p->items lists ALL swept
+/* Whole sweep as ONE persistent launch without level barriers.  p->items lists ALL swept
  * items in (level, id) order (p->nitems of them).  S_idx_wait is p->S_idx with the sign bit set on
  * every edge (i -> j) that item i must wait for (j < i and j swept in this call).  done: int32[n]
  * flags, zero before the first sweep; sweep_id > 0 must increase from call to call.  err: int32[1],

@@ -175,3 +175,75 @@ def test_fused_statistics_equal_the_standalone_pass():
         A._Engine.stats_step = orig
     np.testing.assert_allclose(a.history["train_rmse"], b.history["train_rmse"], atol=3e-6, rtol=0)
     assert abs(a.mu - b.mu) <= 3e-6
+
+
+def test_cfg2_full_size_against_oracle():
+    """BASELINE.json configs[1] at full size (6040 x 3706, 1M ratings, k = 32, explicit bias lambdas):
+    three iterations of the HIP path against the oracle on the same seeded input."""
+    _cuda()
+    from collaborative_filtering_amd import ALS, ALSConfig, BiasesConfig, CoreConfig
+    from oracle.als_oracle import OracleALS, OracleConfig, ratings_from_coo
+    from tests.synth import make_ratings
+    m, n, k = 6040, 3706, 32
+    r, c, v = make_ratings(m, n, 1_000_000, seed=1002)
+    cfg = ALSConfig(core=CoreConfig(n_factors=k, n_iters=3, lambda_u=5.0, lambda_v=6.0),
+                    biases=BiasesConfig(lambda_bu=3.0, lambda_bi=2.0))
+    model = ALS(cfg).fit_coo(r, c, v, (m, n), tol=None, verbose=0)
+    o = OracleALS(OracleConfig(n_factors=k, n_iters=3, lambda_u=5.0, lambda_v=6.0, lambda_bu=3.0,
+                               lambda_bi=2.0)).fit(ratings_from_coo(r, c, v, (m, n)), tol=None)
+    assert np.max(np.abs(np.asarray(model.history["train_rmse"]) - np.asarray(o.history["train_rmse"]))) <= 2e-5
+    _close(model.U, o.U, what="U")
+    _close(model.V, o.V, what="V")
+    np.testing.assert_allclose(model.b_u, o.b_u, atol=2e-4, rtol=0)
+    np.testing.assert_allclose(model.b_i, o.b_i, atol=2e-4, rtol=0)
+
+
+def test_features_mid_size_against_oracle():
+    """W-step at k = 64 with both features on a 5000 x 1500 / 150K-rating problem (the largest the
+    oracle's explicit N_obs x (d k) design matrix allows in a few seconds)."""
+    _cuda()
+    from collaborative_filtering_amd import ALS, ALSConfig, BiasesConfig, CoreConfig
+    from oracle.als_oracle import OracleALS, OracleConfig, ratings_from_coo
+    from tests.synth import make_features, make_ratings
+    m, n, k = 5000, 1500, 64
+    r, c, v = make_ratings(m, n, 150_000, seed=1003)
+    G, Y = make_features(n, 77)
+    feats = {"genres": G, "years": Y}
+    lw = {"genres": 5.0, "years": 10.0}
+    cfg = ALSConfig(core=CoreConfig(n_factors=k, n_iters=3, lambda_u=5.0, lambda_v=6.0, update_w_every=2),
+                    biases=BiasesConfig(lambda_bu=3.0, lambda_bi=2.0))
+    model = ALS(cfg, lambda_w=lw).fit_coo(r, c, v, (m, n), features=feats, tol=None, verbose=0)
+    o = OracleALS(OracleConfig(n_factors=k, n_iters=3, lambda_u=5.0, lambda_v=6.0, lambda_bu=3.0, lambda_bi=2.0,
+                               update_w_every=2, lambda_w=lw)).fit(ratings_from_coo(r, c, v, (m, n)), feats, tol=None)
+    assert np.max(np.abs(np.asarray(model.history["train_rmse"]) - np.asarray(o.history["train_rmse"]))) <= 2e-5
+    for f in feats:
+        _close(model.W[f], o.W[f], what="W_" + f)
+    _close(model.V, o.V, what="V")
+
+
+@pytest.mark.parametrize("k", [16, 50, 128])
+def test_graph_sweep_other_k_against_oracle(k):
+    """The dataflow Laplacian sweep for k != 64 (register solve for k <= 64, streamed solve above),
+    with a precomputed graph and no features, against the oracle."""
+    _cuda()
+    from collaborative_filtering_amd import ALS, ALSConfig, BiasesConfig, CoreConfig, GraphConfig, GraphSimConfig, layout
+    from oracle.als_oracle import OracleALS, OracleConfig, ratings_from_coo
+    from tests.synth import make_features, make_ratings
+    m, n = 400, 300
+    r, c, v = make_ratings(m, n, 9000, seed=500 + k)
+    G, _ = make_features(n, 9)
+    S = layout.build_similarity_dense(G, 8, 1e-8)
+    S_csr = layout.dense_graph_to_csr(S)
+    cfg = ALSConfig(core=CoreConfig(n_factors=k, n_iters=4, lambda_u=3.0, lambda_v=4.0, pop_reg_mode="inverse_sqrt"),
+                    biases=BiasesConfig(lambda_bu=2.0, lambda_bi=1.5),
+                    graph=GraphConfig(alpha=0.8, sim=GraphSimConfig(source="precomputed")))
+    model = ALS(cfg).fit_coo(r, c, v, (m, n), tol=None, verbose=0, S=S_csr)
+    assert model._eng.gs_dataflow and model._eng.fused_stats
+    o = OracleALS(OracleConfig(n_factors=k, n_iters=4, lambda_u=3.0, lambda_v=4.0, pop_reg_mode="inverse_sqrt",
+                               lambda_bu=2.0, lambda_bi=1.5, alpha=0.8, sim={"feature_name": "genres"}))
+    o.fit(ratings_from_coo(r, c, v, (m, n)), {}, tol=None,
+          S_csr=(S_csr[0], S_csr[1].astype(np.int64), S_csr[2]))
+    assert np.max(np.abs(np.asarray(model.history["train_rmse"]) - np.asarray(o.history["train_rmse"]))) <= 2e-5
+    _close(model.V, o.V, what="V")
+    _close(model.U, o.U, what="U")
+    np.testing.assert_allclose(model.b_i, o.b_i, atol=2e-4, rtol=0)
