@@ -11,6 +11,8 @@ from .als import ALS
 from .helpers import (ES_MIN_ITERS, ES_TOL, DEFAULT_RANDOM_STATE, cholesky_solve, make_config,
                       normalize_params, rmse_on_indices)
 
-__all__ = ["ALS", "ALSConfig", "BiasesConfig", "CoreConfig", "GraphConfig", "GraphSimConfig",
+from . import cv                     # sparse CV / ablation harness
+
+__all__ = ["ALS", "cv", "ALSConfig", "BiasesConfig", "CoreConfig", "GraphConfig", "GraphSimConfig",
            "cholesky_solve", "make_config", "normalize_params", "rmse_on_indices",
            "ES_TOL", "ES_MIN_ITERS", "DEFAULT_RANDOM_STATE"]

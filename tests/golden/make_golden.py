@@ -104,7 +104,28 @@ def run_case(name, *, m, n, nnz, seed, k, n_iters, lambda_u, lambda_v,
           f"-> {os.path.getsize(path) / 1024:.0f} KB")
 
 
+def folds_case():
+    """Fold files and a train/valid split produced by the reference's scripts/create_folds.py."""
+    from scripts.create_folds import (load_folds_npz, make_entrywise_folds, make_train_valid_split,
+                                      save_folds_npz)
+    rows, cols, vals = make_ratings(30, 20, 180, 201)
+    R = to_dense(rows, cols, vals, (30, 20))
+    folds = make_entrywise_folds(R, n_splits=5, seed=42, shuffle=True)
+    path = os.path.join(HERE, "ref_folds_30x20.npz")
+    save_folds_npz(path, folds, R.shape, 42)                      # the reference's own file format
+    R_train, R_val, val_idx = make_train_valid_split(R, folds, 2)
+    noshuf = make_entrywise_folds(R, n_splits=4, seed=7, shuffle=False)
+    np.savez_compressed(os.path.join(HERE, "ref_folds_30x20_io.npz"),
+                        rows=rows.astype(np.int32), cols=cols.astype(np.int32), vals=vals.astype(np.float32),
+                        train_flat=np.flatnonzero(~np.isnan(R_train)).astype(np.int64),
+                        train_vals=R_train[~np.isnan(R_train)], val_idx=val_idx.astype(np.int64),
+                        val_vals=R_val.ravel()[val_idx],
+                        **{f"noshuf{i}": f for i, f in enumerate(noshuf)})
+    print("folds fixture:", [len(f) for f in folds])
+
+
 def main():
+    folds_case()
     sim10 = dict(source="feature", feature_name="genres", metric="cosine",
                  topk=10, eps=1e-8)
     # g1: plain U/V (+ the always-on mu / bias terms)

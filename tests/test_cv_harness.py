@@ -1,0 +1,181 @@
+"""the sparse CV / ablation harness (collaborative-filtering_amd/cv.py).
+
+Pinned against the reference where the reference is importable (scripts/create_folds.py: fold files
+and train/valid splits, fixtures tests/golden/ref_folds_30x20*.npz written by make_golden.py); the
+statistics of scripts/evaluate_models.py (not importable: optuna) are checked against scipy and
+hand-computed cases."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from collaborative_filtering_amd import cv
+from tests.common import GOLDEN_DIR, Golden
+
+
+def _fold_fixture():
+    io = np.load(os.path.join(GOLDEN_DIR, "ref_folds_30x20_io.npz"))
+    ratings = cv.CooRatings(io["rows"], io["cols"], io["vals"], (30, 20))
+    return io, ratings
+
+
+def test_folds_equal_the_reference():
+    io, ratings = _fold_fixture()
+    ref_folds, shape, seed = cv.load_folds_npz(os.path.join(GOLDEN_DIR, "ref_folds_30x20.npz"))   # reference-written file
+    assert shape == (30, 20) and seed == 42
+    mine = cv.make_entrywise_folds(ratings, n_splits=5, seed=42, shuffle=True)
+    assert len(mine) == len(ref_folds)
+    for a, b in zip(mine, ref_folds):
+        np.testing.assert_array_equal(a, b)
+    for i, f in enumerate(cv.make_entrywise_folds(ratings, n_splits=4, seed=7, shuffle=False)):
+        np.testing.assert_array_equal(f, io[f"noshuf{i}"])
+
+
+def test_fold_file_round_trip(tmp_path):
+    _, ratings = _fold_fixture()
+    folds = cv.make_entrywise_folds(ratings, 3, seed=5)
+    path = str(tmp_path / "sub" / "folds.npz")
+    cv.save_folds_npz(path, folds, ratings.shape, 5)
+    got, shape, seed = cv.load_folds_npz(path)
+    assert shape == ratings.shape and seed == 5
+    for a, b in zip(got, folds):
+        np.testing.assert_array_equal(a, b)
+    with np.load(path) as z:                                   # same keys / dtypes as the reference's file
+        with np.load(os.path.join(GOLDEN_DIR, "ref_folds_30x20.npz")) as ref:
+            assert {k[:4] for k in z.files} == {k[:4] for k in ref.files}
+            assert z["shape"].dtype == ref["shape"].dtype and z["fold0"].dtype == ref["fold0"].dtype
+
+
+def test_train_valid_split_equals_the_reference():
+    io, ratings = _fold_fixture()
+    folds, _, _ = cv.load_folds_npz(os.path.join(GOLDEN_DIR, "ref_folds_30x20.npz"))
+    (tr, tc, tv), (vr, vc, vv), val_idx = cv.train_valid_split(ratings, folds, 2)
+    np.testing.assert_array_equal(val_idx, io["val_idx"])
+    np.testing.assert_array_equal(np.sort(tr * 20 + tc), io["train_flat"])
+    order = np.argsort(tr * 20 + tc)
+    np.testing.assert_array_equal(tv[order], io["train_vals"])
+    np.testing.assert_array_equal(vv, io["val_vals"])
+    np.testing.assert_array_equal(vr * 20 + vc, val_idx)
+
+
+def test_popularity_bins_and_split():
+    counts = np.array([0, 1, 1, 2, 3, 5, 8, 13, 21, 34], dtype=float)
+    b, edges = cv.popularity_bins(counts, 5, "quantile")
+    assert edges.shape == (6,) and np.all(np.diff(edges) > 0)
+    assert b.min() == 0 and b.max() == 4 and np.all(np.diff(b) >= 0)
+    # every item sits inside its bin's edges (right-most bin closed)
+    for i, c in enumerate(counts):
+        assert edges[b[i]] <= c and (c < edges[b[i] + 1] or b[i] == 4)
+    bu, eu = cv.popularity_bins(counts, 2, "uniform")
+    assert list(bu) == [0, 0, 0, 0, 0, 0, 0, 0, 1, 1] and eu[1] == 17.0
+    with pytest.raises(ValueError):
+        cv.popularity_bins(counts, 3, "kmeans")
+    # degenerate quantiles (many equal counts) still give strictly increasing edges
+    _, e2 = cv.popularity_bins(np.ones(50), 5, "quantile")
+    assert np.all(np.diff(e2) > 0)
+    val_idx = np.array([3, 10 + 9, 20 + 0, 30 + 9])            # n = 10 -> items 3, 9, 0, 9
+    parts = cv.split_by_popularity(val_idx, (4, 10), b, 5)
+    assert sum(len(p) for p in parts) == 4 and list(parts[4]) == [19, 39] and list(parts[0]) == [20]
+
+
+def test_sign_test_and_fdr_against_scipy():
+    from scipy.stats import binomtest, false_discovery_control
+    rng = np.random.default_rng(0)
+    for n in (1, 3, 5, 8):
+        for _ in range(5):
+            x, y = rng.normal(size=n), rng.normal(size=n)
+            k = int(np.sum(x - y > 0))
+            ref = binomtest(k, n, 0.5, alternative="two-sided").pvalue
+            # the reference's doubling rule equals scipy's two-sided p for a symmetric binomial
+            assert abs(cv.sign_test_paired(list(x), list(y)) - min(1.0, ref)) < 1e-12
+    assert cv.sign_test_paired([1.0, 2.0], [1.0, 2.0]) == 1.0           # all ties
+    assert cv.sign_test_paired([1, 1, 1, 1, 1], [0, 0, 0, 0, 0]) == pytest.approx(2 / 32)
+    p = [0.01, 0.04, 0.03, 0.20, 0.5]
+    np.testing.assert_allclose(cv.fdr_bh(p), false_discovery_control(p, method="bh"), rtol=1e-12)
+    assert cv.fdr_bh([]) == []
+
+
+def test_aggregates():
+    agg = cv.aggregate_convergence([[1.0, 0.5, 0.4], [0.8, 0.6]])
+    assert agg["iters"] == [1, 2, 3] and agg["n_folds"] == 2
+    np.testing.assert_allclose(agg["rmse_mean"], [0.9, 0.55, 0.4])
+    np.testing.assert_allclose(agg["rmse_std"], [0.1, 0.05, 0.0])
+    assert cv.aggregate_convergence([]) == {"iters": [], "rmse_mean": [], "rmse_std": [], "n_folds": 0}
+    m = cv.aggregate_bins_mean([{"rmse_pop_1": 1.0, "rmse_pop_2": float("nan")}, {"rmse_pop_1": 3.0, "rmse_pop_2": 2.0}])
+    assert m == {"rmse_pop_1": 2.0, "rmse_pop_2": 2.0}
+    assert np.isnan(cv.rmse_at(np.zeros(0), np.zeros(0)))
+
+
+def test_variant_grid_matches_the_readme_table():
+    """The reference README's ablation table lists: full, no_features, only_genres, only_years,
+    no_graph, graph_feature=years, no_pop_reg (README.md:159-165)."""
+    best = {"n_factors": 8, "n_iters": 20, "lambda_u": 5.0, "lambda_v": 6.0, "lambda_bu": 3.0, "lambda_bi": 2.0,
+            "pop_reg_mode": "inverse_sqrt", "update_w_every": 5, "alpha": 0.5, "graph_feature": "genres",
+            "S_topk": 10, "S_eps": 1e-8, "lambda_w_genres": 5.0, "lambda_w_years": 10.0}
+    names = [n for n, _ in cv.variant_grid(best, ["genres", "years"])]
+    assert names == ["full", "no_features", "only_genres", "only_years", "no_graph", "graph_feature=years", "no_pop_reg"]
+    grid = dict(cv.variant_grid(best, ["genres", "years"]))
+    assert grid["only_years"]["lambda_w_genres"] == 0.0 and grid["only_years"]["lambda_w_years"] == 10.0
+    assert grid["no_graph"]["alpha"] == 0.0 and grid["no_graph"]["graph_feature"] == "__none__"
+    # nothing to ablate -> baseline only; duplicates collapse
+    assert [n for n, _ in cv.variant_grid({"alpha": 0.0, "n_iters": 3}, [])] == ["full"]
+
+
+def test_run_ablation_end_to_end_on_cpu(tmp_path):
+    """Whole driver with the numpy stand-in backend: artifacts, statistics wiring, and fold RMSEs equal
+    to the oracle fitted on the same splits."""
+    from oracle.als_oracle import OracleALS, OracleConfig, ratings_from_coo
+    from tests.cpu_backend import NumpyBackend
+    g = Golden("g2_bias_pop")
+    ratings = cv.CooRatings(g.rows, g.cols, g.vals, (g.m, g.n))
+    folds = cv.make_entrywise_folds(ratings, n_splits=3, seed=42)
+    best = {"n_factors": 8, "n_iters": 4, "lambda_u": 2.0, "lambda_v": 3.0, "lambda_bu": 1.5, "lambda_bi": 2.5,
+            "pop_reg_mode": "inverse_sqrt", "update_w_every": 5, "alpha": 0.0, "graph_feature": "__none__", "S_topk": 10}
+    rows, payload = cv.run_ablation(ratings, folds, {"params": best}, {}, out_dir=str(tmp_path), n_pop_bins=3,
+                                    es_tol=1e-4, es_min_iters=10,
+                                    als_kwargs={"device": "cpu", "backend": NumpyBackend()})
+    assert [r.variant for r in rows] == ["full", "no_pop_reg"]
+    assert rows[0].p_raw is None and rows[1].p_raw is not None and 0.0 <= rows[1].p_fdr <= 1.0
+    assert os.path.exists(tmp_path / "ablations" / "ablations.csv")
+    js = json.loads((tmp_path / "ablations" / "ablations.json").read_text())
+    assert js["variants_evaluated"] == ["full", "no_pop_reg"] and js["matrix_shape"] == [g.m, g.n]
+    assert len(js["pop_bin_edges"]) == 4 and "rmse_pop_3" in js["results"][0]
+    assert json.loads((tmp_path / "ablations" / "convergence" / "full.json").read_text())["n_folds"] == 3
+    for k in range(3):
+        (tr, tc, tv), (_, _, vv), val_idx = cv.train_valid_split(ratings, folds, k)
+        o = OracleALS(OracleConfig(n_factors=8, n_iters=4, lambda_u=2.0, lambda_v=3.0, pop_reg_mode="inverse_sqrt",
+                                   lambda_bu=1.5, lambda_bi=2.5)).fit(ratings_from_coo(tr, tc, tv, (g.m, g.n)),
+                                                                     tol=1e-4, min_iters=10)
+        assert abs(rows[0].fold_rmse[k] - cv.rmse_at(vv, o.predict_at(val_idx))) < 1e-5
+
+
+@pytest.mark.gpu
+def test_eval_variant_cv_on_gpu_matches_oracle():
+    """fit_coo + predict_at per fold on the GPU == the dense reference pipeline restated by the oracle."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected (-m gpu) but no ROCm device is visible")
+    from oracle.als_oracle import OracleALS, ratings_from_coo
+    g = Golden("g4_feat_uw2")
+    ratings = cv.CooRatings(g.rows, g.cols, g.vals, (g.m, g.n))
+    folds = cv.make_entrywise_folds(ratings, n_splits=3, seed=42)
+    params = {"n_factors": 8, "n_iters": 7, "lambda_u": 2.0, "lambda_v": 3.0, "lambda_bu": 1.5, "lambda_bi": 2.5,
+              "pop_reg_mode": "inverse_sqrt", "update_w_every": 2, "alpha": 0.0, "graph_feature": "__none__",
+              "S_topk": 10, "lambda_w_genres": 5.0, "lambda_w_years": 0.0}
+    item_bin, _ = cv.popularity_bins(np.bincount(ratings.cols, minlength=g.n), 3)
+    curves = {}
+    f_rmse, f_time, f_bins, f_iters = cv.eval_variant_cv("full", ratings, g.features, folds, params, item_bin, 3,
+                                                         None, 10, curves)
+    assert f_iters == [7, 7, 7] and len(curves["full"]) == 3
+    cfg = g.oracle_config()
+    cfg.lambda_w = {"genres": 5.0, "years": 0.0}
+    for k in range(3):
+        (tr, tc, tv), (_, _, vv), val_idx = cv.train_valid_split(ratings, folds, k)
+        o = OracleALS(cfg).fit(ratings_from_coo(tr, tc, tv, (g.m, g.n)), g.features, tol=None)
+        assert abs(f_rmse[k] - cv.rmse_at(vv, o.predict_at(val_idx, g.features))) <= 2e-5
+        bins = item_bin[val_idx % g.n]
+        pred = o.predict_at(val_idx, g.features)
+        for b in range(3):
+            ref = cv.rmse_at(vv[bins == b], pred[bins == b])
+            assert (np.isnan(ref) and np.isnan(f_bins[k][f"rmse_pop_{b + 1}"])) or abs(ref - f_bins[k][f"rmse_pop_{b + 1}"]) <= 5e-5
