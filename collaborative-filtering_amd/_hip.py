@@ -16,7 +16,7 @@ SPLIT_CHUNK = 4096          # ALS_SPLIT_CHUNK
 MAX_K = 160                 # ALS_MAX_K
 
 EXPORTS = ("als_version", "als_padded_k", "als_perm_index", "als_partial_slot_bytes",
-           "als_row_solve", "als_gs_sweep", "als_gs_sweep_levels", "als_gs_sweep_dataflow", "als_residual_stats", "als_sum_pairs", "als_sumsq_partials",
+           "als_row_solve", "als_gs_sweep", "als_gs_sweep_levels", "als_gs_sweep_dataflow", "als_residual_stats", "als_w_normal_equations", "als_sum_pairs", "als_sumsq_partials",
            "als_sumsq", "als_compose_z", "als_predict_at", "als_predict_dense")
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -51,6 +51,19 @@ class GsSweepParams(C.Structure):
     ]
 
 
+class WParams(C.Structure):
+    """struct als_w_params (include/als_hip.h)."""
+    _fields_ = [
+        ("k", _i32), ("ld", _i32), ("phase", _i32), ("nfeat", _i32),
+        ("item_begin", _i64), ("item_end", _i64),
+        ("gram", _vp), ("rhs", _vp), ("colsum", _vp), ("V", _vp), ("b_new", _vp), ("b_old", _vp),
+        ("D", _i32), ("reserved", _i32), ("X", _vp), ("feat_off", _vp), ("W", _vp), ("H", _vp),
+        ("nrows_h", _i64),
+        ("feat_index", _i32), ("feat_col0", _i32), ("feat_d", _i32), ("nchunks", _i32),
+        ("partA", _vp), ("partB", _vp), ("A_out", _vp), ("B_out", _vp),
+    ]
+
+
 class HipLibraryMissing(RuntimeError):
     pass
 
@@ -82,6 +95,7 @@ def load():
     lib.als_gs_sweep_dataflow.argtypes = [C.POINTER(GsSweepParams), _vp, _vp, _i32, _vp, _vp]
     lib.als_residual_stats.argtypes = [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _i64, _vp, _vp, _vp]
+    lib.als_w_normal_equations.argtypes = [C.POINTER(WParams), _vp]
     lib.als_sumsq_partials.restype = C.c_int
     lib.als_sumsq.argtypes = [_vp, _i64, _vp, _vp, _vp]
     lib.als_sum_pairs.argtypes = [_vp, _i64, _vp, _vp, _vp]

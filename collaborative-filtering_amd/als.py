@@ -537,8 +537,45 @@ class _Engine:
         and g_i = U_i^T rho_i - G_i z_i follows from the V-step by-products
         (rhs, column sums), so no extra pass over the ratings is needed.  The
         Jacobi-across-features quirk (:474-489) and the lambda=0-for-missing
-        quirk (:497) are kept.  Dense algebra in fp64 (library GEMM + potrf).
+        quirk (:497) are kept.  A_f / b_f come from the HIP kernels of
+        w_step.hip (als_w_normal_equations) in fp64; only the dense (d k)^2
+        Cholesky solve is a library call.
         """
+        if not hasattr(self.be, "w_accumulate"):
+            return self._w_step_host_algebra(b_i_old)        # test stand-in backends only
+        md = self.model
+        k, ld = self.k, self.ld
+        if not hasattr(self, "H"):
+            self.H = torch.zeros(len(self.feat_names), self.n_pad, ld, dtype=torch.float32, device=self.dev)
+            offs = np.concatenate([[0], np.cumsum(self.feat_dims)]).astype(np.int32)
+            self.feat_off_host = offs
+            self.feat_off = torch.from_numpy(offs).to(self.dev)
+        self.be.w_item_vectors(k=k, ld=ld, item_begin=self.ib, item_end=self.ie, gram=self.gram,
+                               rhs=self.rhs_out, colsum=self.colsum_out, V=self.V, b_new=self.b_i,
+                               b_old=b_i_old, X=self.Xcat, feat_off=self.feat_off, W=self.Wcat, H=self.H)
+        pk = self.perm[:k]                          # perm position of storage column c
+        newW = {}
+        for fi, (f, d) in enumerate(zip(self.feat_names, self.feat_dims)):
+            A_full, B_full = self.be.w_accumulate(k=k, ld=ld, item_begin=self.ib, item_end=self.ie,
+                                                  gram=self.gram, X=self.Xcat, H=self.H, feat_index=fi,
+                                                  feat_col0=int(self.feat_off_host[fi]), feat_d=d)
+            if self.world > 1:
+                self._allreduce(A_full)
+                self._allreduce(B_full)
+            sel = (torch.arange(d, device=self.dev)[:, None] * ld + pk[None, :]).reshape(-1)   # (a, c) -> a*ld + perm(c)
+            A = A_full[sel][:, sel].contiguous()
+            B = B_full[sel]
+            A.diagonal().add_(float(md.lambda_w.get(f, 0.0)) + EPS)
+            L, info = torch.linalg.cholesky_ex(A)
+            if int(info.item()) != 0:
+                raise np.linalg.LinAlgError(f"W-step normal equations of feature '{f}' are not positive definite")
+            newW[f] = torch.cholesky_solve(B.reshape(d * k, 1), L).reshape(d, k)
+        self.W64.update(newW)
+        self._sync_wcat()
+
+    def _w_step_host_algebra(self, b_i_old: torch.Tensor):
+        """Same normal equations with torch tensor algebra (fp64).  Used only when the backend has no
+        W kernels, i.e. by the numpy stand-in of the CPU tests; the HIP backend never takes this path."""
         md = self.model
         k, ld = self.k, self.ld
         f64 = torch.float64

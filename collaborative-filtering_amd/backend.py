@@ -117,6 +117,34 @@ class HipBackend:
         self._check(self.lib.als_gs_sweep_levels(C.byref(p), off, len(offsets) - 1, self._stream()),
                     "als_gs_sweep_levels")
 
+    # -- K3/K4 ---------------------------------------------------------------
+    def w_item_vectors(self, *, k, ld, item_begin, item_end, gram, rhs, colsum, V, b_new, b_old, X, feat_off,
+                       W, H):
+        p = _hip.WParams()
+        p.k, p.ld, p.phase, p.nfeat = k, ld, 0, feat_off.numel() - 1
+        p.item_begin, p.item_end = int(item_begin), int(item_end)
+        p.gram, p.rhs, p.colsum, p.V, p.b_new, p.b_old = _p(gram), _p(rhs), _p(colsum), _p(V), _p(b_new), _p(b_old)
+        p.D, p.X, p.feat_off, p.W, p.H, p.nrows_h = X.shape[1], _p(X), _p(feat_off), _p(W), _p(H), H.shape[1]
+        self._check(self.lib.als_w_normal_equations(C.byref(p), self._stream()), "als_w_normal_equations(0)")
+
+    def w_accumulate(self, *, k, ld, item_begin, item_end, gram, X, H, feat_index, feat_col0, feat_d):
+        """(A [(d ld)^2], B [d ld]) fp64 for one feature over items [item_begin, item_end)."""
+        npairs = feat_d * (feat_d + 1) // 2
+        nchunks = max(1, min(64, -(-1024 // npairs)))
+        f64 = torch.float64
+        partA = torch.empty(npairs * nchunks * ld * ld, dtype=f64, device=self.device)
+        partB = torch.empty(feat_d * nchunks * ld, dtype=f64, device=self.device)
+        A = torch.empty(feat_d * ld, feat_d * ld, dtype=f64, device=self.device)
+        B = torch.empty(feat_d * ld, dtype=f64, device=self.device)
+        p = _hip.WParams()
+        p.k, p.ld, p.phase = k, ld, 1
+        p.item_begin, p.item_end = int(item_begin), int(item_end)
+        p.gram, p.D, p.X, p.H, p.nrows_h = _p(gram), X.shape[1], _p(X), _p(H), H.shape[1]
+        p.feat_index, p.feat_col0, p.feat_d, p.nchunks = feat_index, feat_col0, feat_d, nchunks
+        p.partA, p.partB, p.A_out, p.B_out = _p(partA), _p(partB), _p(A), _p(B)
+        self._check(self.lib.als_w_normal_equations(C.byref(p), self._stream()), "als_w_normal_equations(1)")
+        return A, B
+
     # -- K6 ------------------------------------------------------------------
     def residual_stats(self, *, k, ld, side, U, Z, b_u, b_i, mu, tasks, out):
         if tasks.ntasks == 0:

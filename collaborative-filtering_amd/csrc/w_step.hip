@@ -1,0 +1,200 @@
+// K3/K4: normal equations of the feature-projection (W) step.
+//
+// Replaces reference scripts/als.py:469-499 - the N_obs x (d k) design matrix and its Gram are never
+// formed.  With G_i = U_i^T U_i (the item Gram the V-step of the same iteration accumulated,
+// als_row_solve `gram_out`) the reference's ridge system for feature f is
+//     A_f = sum_i (x_i x_i^T) (x) G_i  (+ lambda I, added by the caller)
+//     b_f = sum_i x_i (x) h_{f,i},   h_{f,i} = g_i + G_i xw_{f,i},   g_i = U_i^T rho_i - G_i z_i
+// with rho the residual without any U.Z term, z_i = V_i + sum_f xw_{f,i}, xw_{f,i} = W_f^T x_{f,i}
+// (old W: the reference's Jacobi-across-features quirk, scripts/als.py:474-489).  U_i^T rho_i follows
+// from the V-step by-products: rhs_i - (b_i_new - b_i_old) colsum_i.  Everything is kept in perm space
+// (als_device.hpp); accumulation is fp64.
+//
+//   k_w_item_vectors   one wave per item: h_{f,i} for every feature (perm space, fp32)
+//   k_w_accumulate     one workgroup per (feature-column pair a <= a', item chunk): partial 64x64..160x160
+//                      blocks sum_i x_ia x_ia' G_i and (a == a') partial b rows, skipping zero x
+//   k_w_reduce         fixed-order sum over the chunks, mirrored into the full (d*ld)^2 matrix
+#include "als_device.hpp"
+#include "als_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float gsym(const float* __restrict__ G, int ld, int r, int c) {
+    // G holds the lower 16x16 blocks (block row >= block col) of a symmetric matrix
+    return ((r >> 4) >= (c >> 4)) ? G[r * ld + c] : G[c * ld + r];
+}
+
+// y = G v, v and y one value per lane (perm position p = lane + 64 rr): lane p accumulates
+// sum_j Gsym[j][p] v_j with v_j broadcast by v_readlane
+template <int KB>
+__device__ __forceinline__ void gsym_matvec(const float* __restrict__ G, const int (&p)[KCfg<KB>::NR],
+                                            const float (&v)[KCfg<KB>::NR], float (&y)[KCfg<KB>::NR]) {
+    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) y[rr] = 0.f;
+#pragma unroll 4
+    for (int j = 0; j < KP; ++j) {
+        const float vj = readlane_f(v[j >> 6], j & 63);
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) y[rr] = fmaf(gsym(G, KP, j, p[rr]), vj, y[rr]);
+    }
+}
+
+template <int KB>
+__global__ __launch_bounds__(64)
+void k_w_item_vectors(int k, int64_t i0, int64_t i1, const float* __restrict__ gram,
+                      const float* __restrict__ rhs, const float* __restrict__ colsum,
+                      const float* __restrict__ V, const float* __restrict__ b_new,
+                      const float* __restrict__ b_old, int nfeat, int D, const float* __restrict__ X,
+                      const int* __restrict__ feat_off, const float* __restrict__ W,
+                      float* __restrict__ H, int64_t nrows_h) {
+    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR;
+    const int64_t i = i0 + blockIdx.x;
+    if (i >= i1) return;
+    const int lane = threadIdx.x;
+    const float* G = gram + i * KP * KP;
+    int p[NR], col[NR];
+    float z[NR], gz[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        p[rr] = min(lane + 64 * rr, KP - 1);
+        col[rr] = perm_to_col<KB>(p[rr]);
+        float s = V[i * KP + col[rr]];
+        for (int a = 0; a < D; ++a) s = fmaf(X[i * D + a], W[(int64_t)a * KP + col[rr]], s);    // z = V + sum_f xw_f
+        z[rr] = s;
+    }
+    gsym_matvec<KB>(G, p, z, gz);
+    const float db = b_new[i] - b_old[i];
+    float g[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) g[rr] = rhs[i * KP + p[rr]] - db * colsum[i * KP + p[rr]] - gz[rr];
+    for (int f = 0; f < nfeat; ++f) {
+        float xw[NR], gx[NR];
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            float s = 0.f;
+            for (int a = feat_off[f]; a < feat_off[f + 1]; ++a) s = fmaf(X[i * D + a], W[(int64_t)a * KP + col[rr]], s);
+            xw[rr] = s;
+        }
+        gsym_matvec<KB>(G, p, xw, gx);
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr)
+            if (lane + 64 * rr < KP) H[((int64_t)f * nrows_h + i) * KP + p[rr]] = g[rr] + gx[rr];
+    }
+}
+
+// grid: (npairs, nchunks); block 256.  Thread t owns row r = t >> 2 ... of the KP x KP block in strips.
+template <int KB>
+__global__ __launch_bounds__(256)
+void k_w_accumulate(int64_t i0, int64_t i1, int nchunks, const float* __restrict__ gram, int D, int foff, int d,
+                    const float* __restrict__ X, const float* __restrict__ Hf, double* __restrict__ partA,
+                    double* __restrict__ partB) {
+    constexpr int KP = KCfg<KB>::KP;
+    constexpr int EPT = KP * KP / 256;             // elements per thread (16 at KP = 64)
+    // pair index -> (a, a2), a <= a2
+    int pair = blockIdx.x, a = 0;
+    while (pair >= d - a) { pair -= d - a; ++a; }
+    const int a2 = a + pair;
+    const int chunk = blockIdx.y;
+    const int64_t per = (i1 - i0 + nchunks - 1) / nchunks;
+    const int64_t cb = i0 + chunk * per, ce = min(i1, cb + per);
+    double acc[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) acc[e] = 0.0;
+    double accb = 0.0;                             // thread t < KP: b row entry (only when a == a2)
+    const int t = threadIdx.x;
+    for (int64_t i = cb; i < ce; ++i) {
+        const float xa = X[i * D + foff + a], xb = X[i * D + foff + a2];
+        const float w = xa * xb;
+        if (w == 0.f) continue;                    // block-uniform: every thread reads the same x
+        const float* G = gram + i * KP * KP;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int idx = e * 256 + t;           // consecutive threads -> consecutive columns
+            acc[e] += (double)w * (double)gsym(G, KP, idx / KP, idx % KP);
+        }
+        if (a == a2 && t < KP) accb += (double)xa * (double)Hf[i * KP + t];
+    }
+    double* pA = partA + ((int64_t)blockIdx.x * nchunks + chunk) * KP * KP;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) pA[e * 256 + t] = acc[e];
+    if (a == a2 && t < KP) partB[((int64_t)a * nchunks + chunk) * KP + t] = accb;
+}
+
+template <int KB>
+__global__ __launch_bounds__(256)
+void k_w_reduce(int nchunks, int d, const double* __restrict__ partA, const double* __restrict__ partB,
+                double* __restrict__ A, double* __restrict__ B) {
+    constexpr int KP = KCfg<KB>::KP;
+    int pair = blockIdx.x, a = 0;
+    while (pair >= d - a) { pair -= d - a; ++a; }
+    const int a2 = a + pair;
+    const int64_t N = (int64_t)d * KP;
+    for (int idx = threadIdx.x; idx < KP * KP; idx += 256) {
+        double s = 0.0;
+        for (int c = 0; c < nchunks; ++c) s += partA[((int64_t)blockIdx.x * nchunks + c) * KP * KP + idx];
+        const int r = idx / KP, cc = idx % KP;
+        A[((int64_t)a * KP + r) * N + (int64_t)a2 * KP + cc] = s;
+        A[((int64_t)a2 * KP + cc) * N + (int64_t)a * KP + r] = s;       // each block is symmetric itself
+    }
+    if (a == a2)
+        for (int tt = threadIdx.x; tt < KP; tt += 256) {
+            double s = 0.0;
+            for (int c = 0; c < nchunks; ++c) s += partB[((int64_t)a * nchunks + c) * KP + tt];
+            B[(int64_t)a * KP + tt] = s;
+        }
+}
+
+template <int KB>
+int launch_w(const als_w_params* p, hipStream_t st) {
+    constexpr int KP = KCfg<KB>::KP;
+    const int64_t nit = p->item_end - p->item_begin;
+    if (nit <= 0) return 0;
+    if (p->phase == 0) {
+        hipLaunchKernelGGL(k_w_item_vectors<KB>, dim3((unsigned)nit), dim3(64), 0, st, p->k, p->item_begin,
+                           p->item_end, p->gram, p->rhs, p->colsum, p->V, p->b_new, p->b_old, p->nfeat, p->D,
+                           p->X, p->feat_off, p->W, p->H, p->nrows_h);
+    } else {
+        const int d = p->feat_d, npairs = d * (d + 1) / 2;
+        hipLaunchKernelGGL(k_w_accumulate<KB>, dim3(npairs, p->nchunks), dim3(256), 0, st, p->item_begin,
+                           p->item_end, p->nchunks, p->gram, p->D, p->feat_col0, d, p->X,
+                           p->H + (int64_t)p->feat_index * p->nrows_h * KP, p->partA, p->partB);
+        hipLaunchKernelGGL(k_w_reduce<KB>, dim3(npairs), dim3(256), 0, st, p->nchunks, d, p->partA, p->partB,
+                           p->A_out, p->B_out);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int als_w_normal_equations(const als_w_params* p, void* stream) {
+    if (!p) return ALS_E_BADARG;
+    const int ld = als_padded_k(p->k);
+    if (ld < 0) return ALS_E_BADK;
+    if (p->ld != ld || !p->gram || !p->X || !p->H || p->D <= 0 || p->item_end < p->item_begin) return ALS_E_BADARG;
+    if (p->phase == 0) {
+        if (!p->rhs || !p->colsum || !p->V || !p->b_new || !p->b_old || !p->feat_off || !p->W ||
+            p->nfeat < 1 || p->nfeat > 8)
+            return ALS_E_BADARG;
+    } else if (p->phase == 1) {
+        if (!p->partA || !p->partB || !p->A_out || !p->B_out || p->feat_d < 1 || p->nchunks < 1 ||
+            p->feat_index < 0 || p->feat_col0 < 0 || p->feat_col0 + p->feat_d > p->D)
+            return ALS_E_BADARG;
+    } else {
+        return ALS_E_BADARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    switch (ld / 16) {
+        case 1: return launch_w<1>(p, st);
+        case 2: return launch_w<2>(p, st);
+        case 3: return launch_w<3>(p, st);
+        case 4: return launch_w<4>(p, st);
+        case 5: return launch_w<5>(p, st);
+        case 6: return launch_w<6>(p, st);
+        case 7: return launch_w<7>(p, st);
+        case 8: return launch_w<8>(p, st);
+        case 9: return launch_w<9>(p, st);
+        case 10: return launch_w<10>(p, st);
+    }
+    return ALS_E_BADK;
+}

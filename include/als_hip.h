@@ -204,6 +204,44 @@ int als_residual_stats(int k, int ld, const int64_t* indptr, const int32_t* indi
                        const als_task* tasks, int64_t ntasks,
                        double* partials, double* out, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * als_w_normal_equations - normal equations of the feature-projection step,
+ * replaces scripts/als.py:469-499 (the N_obs x (d k) design matrix is never formed).
+ *   phase 0: per-item vectors h_{f,i} = g_i + G_i xw_{f,i} for all features (H, perm space),
+ *            from the V-step by-products gram/rhs/colsum (als_row_solve), the new and old item
+ *            bias, V and the OLD projections W (Jacobi across features, as the reference).
+ *   phase 1: for ONE feature (columns feat_col0 .. +feat_d of X): A_out [(d*ld)^2] =
+ *            sum_i (x_i x_i^T) (x) G_i and B_out [d*ld] = sum_i x_i (x) h_{f,i}, fp64, perm space,
+ *            padded positions included (the caller selects the k real ones and adds lambda).
+ * Items [item_begin, item_end) only (a rank's shard); A/B are then all-reduced by the caller.
+ * ------------------------------------------------------------------------- */
+typedef struct als_w_params {
+    int32_t k, ld;
+    int32_t phase;                 /* 0: item vectors, 1: accumulate one feature */
+    int32_t nfeat;                 /* phase 0: number of features (<= 8) */
+    int64_t item_begin, item_end;
+    const float* gram;             /* [n][ld][ld] lower blocks (als_row_solve gram_out) */
+    const float* rhs;              /* [n][ld] perm  (rhs_out)    */
+    const float* colsum;           /* [n][ld] perm  (colsum_out) */
+    const float* V;                /* [n][ld] */
+    const float* b_new;            /* [n] item bias after the V-step  */
+    const float* b_old;            /* [n] item bias before the V-step */
+    int32_t D;                     /* total feature columns of X */
+    int32_t reserved;
+    const float* X;                /* [n][D] all features side by side */
+    const int32_t* feat_off;       /* device int32 [nfeat+1] column offsets (phase 0) */
+    const float* W;                /* [D][ld] old projections, storage column order (phase 0) */
+    float* H;                      /* [nfeat][nrows_h][ld] (phase 0 writes, phase 1 reads) */
+    int64_t nrows_h;
+    int32_t feat_index, feat_col0, feat_d, nchunks;   /* phase 1 */
+    double* partA;                 /* scratch: d(d+1)/2 * nchunks * ld*ld doubles */
+    double* partB;                 /* scratch: d * nchunks * ld doubles */
+    double* A_out;                 /* [(d*ld)][(d*ld)] */
+    double* B_out;                 /* [d*ld] */
+} als_w_params;
+
+int als_w_normal_equations(const als_w_params* p, void* stream);
+
 /* out[0] = sum_i x[2i], out[1] = sum_i x[2i+1] in fp64 (reduction of stat_out).
  * partials: scratch of 2*als_sumsq_partials() doubles. */
 int als_sum_pairs(const float* x, int64_t npairs, double* partials, double* out, void* stream);
