@@ -33,6 +33,29 @@ EPS = 1e-10             # scripts/als.py:94
 
 logger = logging.getLogger(__name__)
 
+# The similarity graph depends only on (feature matrix, topk, eps); CV harnesses refit with the same
+# features fold after fold (scripts/evaluate_models.py:242), so the O(n^2 d) host build is memoised by
+# content.  Two entries: a dense n x n float32 S is 99 MB at n = 4980.
+_SIM_CACHE: "dict" = {}
+_SIM_CACHE_MAX = 2
+
+
+def _similarity_cached(X: np.ndarray, topk, eps):
+    import hashlib
+    Xc = np.ascontiguousarray(X)
+    key = (hashlib.blake2b(Xc.view(np.uint8).reshape(-1), digest_size=16).hexdigest(), str(Xc.dtype), Xc.shape,
+           topk, float(eps))
+    hit = _SIM_CACHE.pop(key, None)
+    if hit is None:
+        Sd = layout.build_similarity_dense(X, topk, eps)
+        ptr, idx, val = layout.dense_graph_to_csr(Sd)
+        # D = S.sum(axis=1) exactly as the reference forms it (scripts/als.py:357)
+        hit = (Sd, (ptr, idx, val.astype(np.float32), Sd.sum(axis=1).astype(np.float32)))
+    _SIM_CACHE[key] = hit                      # most recently used last
+    while len(_SIM_CACHE) > _SIM_CACHE_MAX:
+        _SIM_CACHE.pop(next(iter(_SIM_CACHE)))
+    return hit
+
 
 @dataclass
 class _SideDev:
@@ -186,11 +209,7 @@ class ALS:
                     logger.warning("GraphSim feature '%s' not found in features dict. "
                                    "Graph regularization disabled.", self.cfg.graph.sim.feature_name)
                 else:
-                    Sd = layout.build_similarity_dense(X, self.S_topk, self.S_eps)
-                    self.S = Sd
-                    ptr, idx, val = layout.dense_graph_to_csr(Sd)
-                    # D = S.sum(axis=1) exactly as the reference forms it (:357)
-                    S_csr = (ptr, idx, val.astype(np.float32), Sd.sum(axis=1).astype(np.float32))
+                    self.S, S_csr = _similarity_cached(X, self.S_topk, self.S_eps)
 
         device = self._device or torch.device("cuda", torch.cuda.current_device()
                                               if torch.cuda.is_available() else 0)
