@@ -323,15 +323,21 @@ def main():
         by = (4 * k + 12) * (nn_u + nn_i) + (4 * k + 12) * (rows_u + rows_i)
         t_rs = 1e-3 * sum(rs_ms) / args.steps            # seconds per iteration in row-solve launches
         n_launch = 2
+        # Primary view: HBM.  With the Gram on the bf16 matrix cores the binding resources of this kernel are
+        # the gather of 256-B factor rows (V-step launch: U does not fit the caches) and VALU issue (U-step
+        # launch); the fp32-matrix view (k = 64 was fp32-MFMA-bound) is kept as `mfma_view`.
         roof = {"kernel": "k_row_tasks<KB=4> (als_row_solve; U-step and V-step launches)",
-                "bound": "mfma", "achieved": fl / t_rs / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                "peak_note": "dense fp32 matrix peak (the arithmetic is fp32-equivalent; in gram=bf16x3 mode the "
-                             "Gram issues 6 bf16 MFMAs per block on the 2.5 PFLOP/s bf16 pipe instead)",
-                "frac": fl / t_rs / 1e12 / 157.3,
+                "bound": "hbm", "achieved": by / t_rs / 1e9, "peak": 8000.0, "unit": "GB/s",
+                "frac": by / t_rs / 1e9 / 8000.0,
                 "avg_launch_ms": 1e3 * t_rs / n_launch,
-                "algorithmic_flops_per_launch": fl / n_launch,
-                "hbm_view": {"achieved_GBps": by / t_rs / 1e9, "peak_GBps": 8000.0,
-                             "frac": by / t_rs / 1e9 / 8000.0, "algorithmic_bytes_per_launch": by / n_launch},
+                "algorithmic_bytes_per_launch": by / n_launch,
+                "per_launch": {nm: {"ms": sum(phase.get(nm, [0.0])) / args.steps,
+                                    "algorithmic_GBps": (4 * k + 12) * (nn + rr) / (1e-3 * sum(phase.get(nm, [1e-9])) / args.steps) / 1e9}
+                               for nm, nn, rr in (("row_solve_user", nn_u, rows_u), ("row_solve_item", nn_i, rows_i))},
+                "mfma_view": {"achieved_TFLOPs": fl / t_rs / 1e12, "peak_TFLOPs": 157.3, "frac": fl / t_rs / 1e12 / 157.3,
+                              "algorithmic_flops_per_launch": fl / n_launch,
+                              "note": "full-Gram fp32 flops of SURVEY 8(d) against the dense fp32 matrix peak; the kernel "
+                                      "issues 10/16 of them, in gram=bf16x3 mode as 6 bf16 MFMAs per block"},
                 "traffic": None}
         # HBM bytes per launch from the committed PMC pass (profiles/collect_pmc.sh; FETCH_SIZE doubled as
         # MI355X_MICROARCH.md prescribes for gfx950) - only meaningful for the workload it was taken on
@@ -342,7 +348,7 @@ def main():
             roof["traffic_source"] = os.path.relpath(pm[-1], ROOT)
         # the kernel exploits the symmetry of the Gram (10 of 16 blocks): matrix-core work actually issued
         fl_exec = (2 * k * k * 10 / 16 + 4 * k) * (nn_u + nn_i)
-        roof["executed_gram_frac_of_peak"] = fl_exec / t_rs / 1e12 / 157.3
+        roof["mfma_view"]["executed_gram_frac_of_fp32_peak"] = fl_exec / t_rs / 1e12 / 157.3
         out = {
             "metric": "ratings/sec per ALS iteration at k=64", "value": nnz / (elapsed / args.steps),
             "unit": "ratings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -260,6 +260,8 @@ class ALS:
 class _Engine:
     """Device state and the iteration loop of one `fit`."""
 
+    U_CHUNKS = 4        # sub-ranges of a rank's user shard (multi-rank runs only)
+
     def __init__(self, model: ALS, csr, csc, features, S_csr, device, backend, pg, gs_mode):
         self.model = model
         self.dev = device
@@ -278,7 +280,9 @@ class _Engine:
         f32, f64 = torch.float32, torch.float64
 
         # --- shards (contiguous, equal row counts; storage padded to world * per)
-        self.u_per, ub = layout.shard_bounds(self.m, self.world)
+        # the user shard is solved in U_CHUNKS sub-ranges whose all-gathers overlap the next sub-range's solve
+        self.u_chunks = self.U_CHUNKS if self.world > 1 else 1
+        self.u_per, ub = layout.shard_bounds(self.m, self.world, self.u_chunks)
         self.i_per, ib = layout.shard_bounds(self.n, self.world)
         self.ub, self.ue = ub[self.rank]
         self.ib, self.ie = ib[self.rank]
@@ -292,6 +296,14 @@ class _Engine:
         iptr_h = self.csc.indptr.cpu().numpy()
         self.utasks = _tasks_to_dev(layout.build_row_tasks(uptr_h, self.ub, self.ue), device)
         self.itasks = _tasks_to_dev(layout.build_row_tasks(iptr_h, self.ib, self.ie), device)
+        if self.u_chunks > 1:
+            sub = self.u_per // self.u_chunks
+            lo0 = self.rank * self.u_per
+            self.utasks_c = [_tasks_to_dev(layout.build_row_tasks(uptr_h, min(lo0 + c * sub, self.m),
+                                                                  min(lo0 + (c + 1) * sub, self.m)), device)
+                             for c in range(self.u_chunks)]
+            self.u_stage = torch.empty(self.u_chunks, self.world, sub, self.ld, dtype=torch.float32, device=device)
+            self.bu_stage = torch.empty(self.u_chunks, self.world, sub, dtype=torch.float32, device=device)
         nslots = max(self.utasks.nslots, self.itasks.nslots)
         self.workspace = (torch.empty(nslots * backend.slot_bytes(k) // 4, dtype=f32, device=device)
                           if nslots else None)
@@ -447,18 +459,40 @@ class _Engine:
 
     # ---------------------------------------------------------- half steps
     def user_step(self):
-        """scripts/als.py:414-433 on this rank's user shard, then all-gather."""
+        """scripts/als.py:414-433 on this rank's user shard, then all-gather.
+
+        With several ranks the shard is solved in U_CHUNKS contiguous sub-ranges; the all-gather of a
+        finished sub-range (async, on the collective stream) overlaps the solve of the next one.
+        """
         md = self.model
+        kw = dict(k=self.k, ld=self.ld, side=self.csr, F=self.Z, zero_row=self.n_pad, bias_self=self.b_u,
+                  bias_other=self.b_i, mu=self.mu, lam=md.lambda_u, lam_row=None, lam_b=md.lambda_bu,
+                  lam_b_row=None, rhs_extra=None, diag_extra=None, X_out=self.U, bias_out=self.b_u,
+                  gram_out=None, factor_out=None, rhs_out=None, colsum_out=None, sumr_out=None,
+                  status=self.status, workspace=self.workspace)
+        if self.u_chunks == 1:
+            with self._tick("row_solve_user"):
+                self.be.row_solve(tasks=self.utasks, **kw)
+            self._allgather_rows(self.U, self.u_per)
+            self._allgather_rows(self.b_u, self.u_per)
+            return
+        C, sub, lo0 = self.u_chunks, self.u_per // self.u_chunks, self.rank * self.u_per
+        works = []
         with self._tick("row_solve_user"):
-            self.be.row_solve(k=self.k, ld=self.ld, side=self.csr, F=self.Z, zero_row=self.n_pad,
-                              bias_self=self.b_u,
-                              bias_other=self.b_i, mu=self.mu, lam=md.lambda_u, lam_row=None,
-                              lam_b=md.lambda_bu, lam_b_row=None, rhs_extra=None, diag_extra=None,
-                              X_out=self.U, bias_out=self.b_u, gram_out=None, factor_out=None,
-                              rhs_out=None, colsum_out=None, sumr_out=None, status=self.status,
-                              tasks=self.utasks, workspace=self.workspace)
-        self._allgather_rows(self.U, self.u_per)
-        self._allgather_rows(self.b_u, self.u_per)
+            for c in range(C):
+                if self.utasks_c[c].ntasks or self.utasks_c[c].nlong:
+                    self.be.row_solve(tasks=self.utasks_c[c], **kw)
+                rows = slice(lo0 + c * sub, lo0 + (c + 1) * sub)
+                works.append(dist.all_gather_into_tensor(self.u_stage[c].view(-1), self.U[rows].reshape(-1),
+                                                         group=self.pg, async_op=True))
+                works.append(dist.all_gather_into_tensor(self.bu_stage[c].view(-1), self.b_u[rows].reshape(-1),
+                                                         group=self.pg, async_op=True))
+        with self._tick("allgather_user_wait"):
+            for w in works:
+                w.wait()
+            # stage[c][g] holds rows [g*per + c*sub, +sub) of rank g
+            self.U.view(self.world, C, sub, self.ld).copy_(self.u_stage.transpose(0, 1))
+            self.b_u.view(self.world, C, sub).copy_(self.bu_stage.transpose(0, 1))
 
     def item_step(self, want_gram: bool):
         """scripts/als.py:436-466 on this rank's item shard, then all-gather.

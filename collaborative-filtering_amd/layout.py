@@ -126,9 +126,11 @@ def build_row_tasks(indptr: np.ndarray, row_begin: int = 0, row_end: Optional[in
     return RowTasks(tasks, long_rows, nslots, int(cnt.sum()))
 
 
-def shard_bounds(nrows: int, world: int) -> Tuple[int, List[Tuple[int, int]]]:
-    """Equal contiguous row shards: (rows per shard, [(begin, end) per rank])."""
+def shard_bounds(nrows: int, world: int, multiple: int = 1) -> Tuple[int, List[Tuple[int, int]]]:
+    """Equal contiguous row shards: (rows per shard, [(begin, end) per rank]); rows per shard is
+    rounded up to a multiple of `multiple` (sub-chunks of a shard then have equal sizes too)."""
     per = (nrows + world - 1) // world
+    per = ((per + multiple - 1) // multiple) * multiple
     return per, [(min(r * per, nrows), min((r + 1) * per, nrows)) for r in range(world)]
 
 
