@@ -358,11 +358,11 @@ class _Engine:
             idx = self.S_idx.cpu().numpy()
             if len(S_csr) > 3:
                 D = _to_dev(S_csr[3], device, f32)
-            else:                       # D = S.sum(axis=1) in S's dtype (scripts/als.py:357)
-                D = torch.zeros(self.n, dtype=f32, device=device)
-                rows_of = torch.repeat_interleave(torch.arange(self.n, device=device),
-                                                  self.S_ptr[1:] - self.S_ptr[:-1])
-                D.index_add_(0, rows_of, self.S_val)
+            else:                       # D = S.sum(axis=1) (scripts/als.py:357); segment sums from an fp64
+                # prefix sum: deterministic (index_add_ would use float atomics)
+                csum = torch.zeros(self.S_val.numel() + 1, dtype=f64, device=device)
+                csum[1:] = torch.cumsum(self.S_val.to(f64), 0)
+                D = (csum[self.S_ptr[1:]] - csum[self.S_ptr[:-1]]).to(f32)
             self.diag_extra = torch.zeros(n_pad, dtype=f32, device=device)
             self.diag_extra[: self.n] = np.float32(model.alpha) * D
             self.gs_mode = gs_mode or ("exact" if self.world == 1 else "block")

@@ -216,14 +216,14 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
             const int raw = (lane < nn) ? Sw[t0 + lane] : item;
             const int sj_l = raw & 0x7fffffff;
             const float sv_l = (lane < nn) ? P.S_val[t0 + lane] : 0.f;
-            // Pass 1: one look at the flags; every neighbour that is not a dependency, or whose
-            // dependency is already met, is gathered now (weight 0 for the rest) - typically all
-            // but the few rows of the immediately preceding levels.
+            // Pass 1: every neighbour that is NOT a dependency (j > i, or not swept) is gathered right
+            // away.  Pass 2: the dependencies, always in ascending position order and 16 per batch, each
+            // batch as soon as all its flags are up.  The order of the floating-point sum therefore never
+            // depends on timing: the sweep is bitwise reproducible.
             const bool need = raw < 0;
-            bool ok = !need || (__hip_atomic_load(done + sj_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sweep_id);
-            const float sv_now = ok ? sv_l : 0.f;
+            const float sv_now = need ? 0.f : sv_l;
             constexpr int GB = (NR == 1) ? 16 : 8;
-            for (int e0 = 0; e0 < nn; e0 += GB) {
+            for (int e0 = 0; e0 < nn; e0 += GB) {     // (dependency lanes ride along with weight 0)
                 float vv[GB][NR], sv[GB];
 #pragma unroll
                 for (int e = 0; e < GB; ++e) {
@@ -237,46 +237,69 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
 #pragma unroll
                     for (int rr = 0; rr < NR; ++rr) g[rr] = fmaf(sv[e], vv[e][rr], g[rr]);
             }
-            // Pass 2: the outstanding dependencies, fetched as they complete (a timeout anywhere is
-            // sticky: nobody waits after it)
-            unsigned long long pend = __ballot(!ok);
-            if (pend) {
-                const unsigned long long tstart = __builtin_amdgcn_s_memtime();
-                bool bail = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                while (pend) {
-                    if (!ok) ok = bail || (__hip_atomic_load(done + sj_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sweep_id);
-                    unsigned long long rdy = __ballot(ok) & pend;
-                    pend &= ~rdy;
-                    while (rdy) {                       // up to 4 freshly completed rows per round trip
-                        int e[4];
-                        float w[4], v[4][NR];
+            // Dependencies: batches of GB in ascending position order.  A batch is gathered into ITS OWN
+            // partial sum as soon as all its flags are up (ready batches first, late ones after), and the
+            // partials are added in batch order at the end - processing order follows readiness, the order
+            // of the floating-point sum does not.
+            constexpr int NB = 64 / GB;
+            unsigned long long dep = __ballot(need);
+            if (dep) {
+                bool ok = !need || (__hip_atomic_load(done + sj_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sweep_id);
+                unsigned long long bm[NB];
+                float gp[NB][NR];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            e[u] = rdy ? (int)__builtin_ctzll(rdy) : -1;
-                            if (rdy) rdy &= rdy - 1;
+                for (int bb = 0; bb < NB; ++bb) {
+                    unsigned long long m = 0;
+#pragma unroll
+                    for (int u = 0; u < GB; ++u)
+                        if (dep) { m |= dep & (~dep + 1); dep &= dep - 1; }
+                    bm[bb] = m;
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr) gp[bb][rr] = 0.f;
+                }
+                bool bail = false;
+#pragma unroll
+                for (int round = 0; round < 2; ++round) {
+#pragma unroll
+                    for (int bb = 0; bb < NB; ++bb) {
+                        if (bm[bb] == 0) continue;
+                        const bool mine = (bm[bb] >> lane) & 1;
+                        if (!bail && !__all(ok || !mine)) {
+                            if (round == 0) continue;                 // not ready yet: after the ready ones
+                            const unsigned long long tstart = __builtin_amdgcn_s_memtime();
+                            bail = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                            while (!bail && !__all(ok || !mine)) {    // a timeout anywhere is sticky
+                                __builtin_amdgcn_s_sleep(1);
+                                if (!ok) ok = __hip_atomic_load(done + sj_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sweep_id;
+                                if (__builtin_amdgcn_s_memtime() - tstart > SPIN_LIMIT ||
+                                    __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                                    if (lane == 0) atomicExch(err, 1);
+                                    bail = true;
+                                }
+                            }
                         }
+                        unsigned long long m = bm[bb];
+                        bm[bb] = 0;
+                        float w[GB], v[GB][NR];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int src = e[u] < 0 ? 0 : e[u];
+                        for (int u = 0; u < GB; ++u) {
+                            const int src = m ? (int)__builtin_ctzll(m) : 0;
+                            w[u] = m ? __shfl(sv_l, src, 64) : 0.f;
                             const int sj = __shfl(sj_l, src, 64);
-                            w[u] = e[u] < 0 ? 0.f : __shfl(sv_l, src, 64);
+                            if (m) m &= m - 1;
 #pragma unroll
                             for (int rr = 0; rr < NR; ++rr) v[u][rr] = ld_agent(P.V + (int64_t)sj * P.ld + col[rr]);
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
+                        for (int u = 0; u < GB; ++u)
 #pragma unroll
-                            for (int rr = 0; rr < NR; ++rr) g[rr] = fmaf(w[u], v[u][rr], g[rr]);
-                    }
-                    if (pend) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (__builtin_amdgcn_s_memtime() - tstart > SPIN_LIMIT ||
-                            __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                            if (lane == 0) atomicExch(err, 1);
-                            bail = true;
-                        }
+                            for (int rr = 0; rr < NR; ++rr) gp[bb][rr] = fmaf(w[u], v[u][rr], gp[bb][rr]);
                     }
                 }
+#pragma unroll
+                for (int bb = 0; bb < NB; ++bb)
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr) g[rr] += gp[bb][rr];
             }
         }
         float x[NR], y[NR];
@@ -325,8 +348,9 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
 template <int KB>
 int launch_gs_dataflow(const als_gs_sweep_params* p, const int32_t* Sw, int32_t* done, int sweep_id,
                        int32_t* err, int64_t nitems, hipStream_t st) {
-    // one 4-wave workgroup per CU: 1024 waves are always co-resident on the 256-CU part
-    int nwg = 256;
+    // two 4-wave workgroups per CU (<= 222 VGPRs, no LDS: at least 2 waves per SIMD fit): 2048 waves
+    // are always co-resident on the 256-CU part
+    int nwg = 512;
     if ((int64_t)nwg * 4 > nitems) nwg = (int)((nitems + 3) / 4);
     if (nwg < 1) return 0;
     hipLaunchKernelGGL(k_gs_dataflow<KB>, dim3(nwg), dim3(256), 0, st, *p, Sw, done, sweep_id, err, nitems, nwg * 4);

@@ -20,8 +20,10 @@
 namespace {
 
 __device__ __forceinline__ float gsym(const float* __restrict__ G, int ld, int r, int c) {
-    // G holds the lower 16x16 blocks (block row >= block col) of a symmetric matrix
-    return ((r >> 4) >= (c >> 4)) ? G[r * ld + c] : G[c * ld + r];
+    // G holds the lower 16x16 blocks (block row >= block col) of a symmetric matrix.  The two halves of a
+    // diagonal block come from different accumulation orders and are equal only to rounding: always read
+    // the lower-triangle element, so that gsym(r, c) == gsym(c, r) bitwise.
+    return (r >= c) ? G[r * ld + c] : G[c * ld + r];
 }
 
 // y = G v, v and y one value per lane (perm position p = lane + 64 rr): lane p accumulates

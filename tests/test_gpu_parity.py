@@ -132,6 +132,13 @@ def test_run_to_run_bitwise_reproducible():
     b = _model_for(g).fit_coo(r, c, v, (g.m, g.n), tol=None, verbose=0)
     assert np.array_equal(a.U, b.U) and np.array_equal(a.V, b.V)
     assert a.history["train_rmse"] == b.history["train_rmse"]
+    # with the Laplacian: the dataflow sweep sums in a timing-independent order
+    g = Golden("g5_graph_a0.5")
+    r, c, v = g.train
+    runs = [_model_for(g).fit_coo(r, c, v, (g.m, g.n), features=g.features, tol=None, verbose=0) for _ in range(3)]
+    for other in runs[1:]:
+        assert np.array_equal(runs[0].V, other.V) and np.array_equal(runs[0].U, other.U)
+        assert runs[0].history["train_rmse"] == other.history["train_rmse"]
 
 
 @pytest.mark.parametrize("name", ["g5_graph_a0.5", "g5_graph_a5.0"])
