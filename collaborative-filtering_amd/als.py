@@ -9,7 +9,7 @@ per-row / per-rating step runs in the HIP kernels behind include/als_hip.h.
 
 Build-only additions (keyword arguments with defaults, so the reference
 signature is unchanged):
-  ALS(..., device=, backend=, gs_mode=, process_group=, gram=)
+  ALS(..., device=, backend=, gs_mode=, process_group=, gram=, graph_build=)
   fit(..., S=)              precomputed similarity graph as CSR (ptr, idx, val)
   fit_coo(rows, cols, vals, shape, ...)   sparse-native entry for large inputs
   predict_at(flat_idx, ...) predictions at flat indices u*n+i without the
@@ -115,7 +115,7 @@ class ALS:
 
     def __init__(self, config: ALSConfig, lambda_w: Optional[Dict[str, float]] = None, *,
                  device=None, backend=None, gs_mode: Optional[str] = None, process_group=None,
-                 gram: Optional[str] = None) -> None:
+                 gram: Optional[str] = None, graph_build: str = "host") -> None:
         if config is None:                                   # scripts/als.py:146-147
             raise ValueError("ALSConfig must be provided.")
         self.cfg = config
@@ -147,6 +147,9 @@ class ALS:
         self._gs_mode = gs_mode
         self._pg = process_group
         self._gram = gram               # "bf16x3" (default) or "f32": how K1 forms the Gram on the matrix cores
+        if graph_build not in ("host", "device"):
+            raise ValueError("graph_build must be 'host' (reference-identical, dense n x n) or 'device'")
+        self._graph_build = graph_build
         self._eng: Optional[_Engine] = None
 
     # ------------------------------------------------------------------ fit
@@ -208,6 +211,10 @@ class ALS:
                 if X is None:                                # scripts/als.py:219-222
                     logger.warning("GraphSim feature '%s' not found in features dict. "
                                    "Graph regularization disabled.", self.cfg.graph.sim.feature_name)
+                elif self._graph_build == "device":
+                    dev = self._device or torch.device("cuda", torch.cuda.current_device())
+                    S_csr = layout.build_similarity_device(X, self.S_topk, self.S_eps, dev)
+                    self.S = S_csr[:3]
                 else:
                     self.S, S_csr = _similarity_cached(X, self.S_topk, self.S_eps)
 

@@ -153,6 +153,53 @@ def build_similarity_dense(X: np.ndarray, topk: Optional[int], eps: float) -> np
     return np.maximum(S, S.T)
 
 
+def build_similarity_device(X, topk: Optional[int], eps: float, device, block: int = 4096):
+    """Device-side build of the same graph as `build_similarity_dense`, without the n x n matrix
+    (SURVEY section 8(f) n2): blocked cosine products, per-row top-k, symmetrised by max, returned as CSR
+    (ptr int64, idx int32, val float32, D float32) device tensors.
+
+    NOT tie-identical to the reference: among equal similarities at the top-k boundary numpy's
+    `argpartition` (scripts/als.py:235) keeps an implementation-defined subset, here the lowest
+    column indices win.  With all-distinct similarities the graphs are identical.  Zero similarities
+    are not edges, as in the dense form.  Opt-in (`ALS(..., graph_build="device")`); the host build
+    stays the default because binary features (genres) tie massively.
+    """
+    import torch
+    Xd = torch.as_tensor(np.asarray(X), device=device)
+    n = Xd.shape[0]
+    Xn = Xd / (torch.sqrt((Xd * Xd).sum(1, keepdim=True)) + eps)
+    keep_all = topk is None or topk >= n
+    rows, cols, vals = [], [], []
+    for b in range(0, n, block):
+        e = min(b + block, n)
+        Sb = Xn[b:e] @ Xn.T                                   # [e-b, n] in X's dtype
+        ar = torch.arange(b, e, device=device)
+        Sb[ar - b, ar] = 0.0
+        if keep_all:
+            nz = torch.nonzero(Sb)
+            rows.append(nz[:, 0] + b); cols.append(nz[:, 1]); vals.append(Sb[nz[:, 0], nz[:, 1]])
+        else:
+            # stable descending sort: equal values keep ascending column order -> lowest indices win
+            tv, ti = torch.sort(Sb, dim=1, descending=True, stable=True)
+            tv, ti = tv[:, :topk], ti[:, :topk]
+            ok = tv != 0
+            rows.append(ar[:, None].expand(-1, topk)[ok]); cols.append(ti[ok]); vals.append(tv[ok])
+    r = torch.cat(rows).to(torch.int64); c = torch.cat(cols).to(torch.int64); v = torch.cat(vals)
+    key = torch.cat([r * n + c, c * n + r])                 # max(S, S^T): both orientations, reduce by max
+    val = torch.cat([v, v])
+    uk, inv = torch.unique(key, return_inverse=True)
+    sv = torch.full((uk.numel(),), -float("inf"), dtype=val.dtype, device=device).scatter_reduce_(0, inv, val, reduce="amax")
+    sr = torch.div(uk, n, rounding_mode="floor")
+    sc = uk - sr * n
+    ptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    ptr[1:] = torch.cumsum(torch.bincount(sr, minlength=n), 0)
+    sv32 = sv.to(torch.float32)
+    csum = torch.zeros(sv.numel() + 1, dtype=torch.float64, device=device)
+    csum[1:] = torch.cumsum(sv.to(torch.float64), 0)
+    D = (csum[ptr[1:]] - csum[ptr[:-1]]).to(torch.float32)
+    return ptr, sc.to(torch.int32), sv32, D
+
+
 def dense_graph_to_csr(S: np.ndarray):
     ri, ci = np.nonzero(S)
     ptr = np.zeros(S.shape[0] + 1, dtype=np.int64)

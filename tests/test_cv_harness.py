@@ -179,3 +179,24 @@ def test_eval_variant_cv_on_gpu_matches_oracle():
         for b in range(3):
             ref = cv.rmse_at(vv[bins == b], pred[bins == b])
             assert (np.isnan(ref) and np.isnan(f_bins[k][f"rmse_pop_{b + 1}"])) or abs(ref - f_bins[k][f"rmse_pop_{b + 1}"]) <= 5e-5
+
+
+def test_device_graph_build_equals_host_build_without_ties():
+    """blocked device build == the reference-style dense host build whenever the
+    similarities are all distinct (continuous features); runs on CPU tensors here."""
+    import torch
+    from collaborative_filtering_amd import layout
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(300, 7)).astype(np.float32)
+    for topk in (5, 40, None):
+        Sd = layout.build_similarity_dense(X.copy(), topk, 1e-8)
+        hp, hi, hv = layout.dense_graph_to_csr(Sd)
+        dp, di, dv, dD = layout.build_similarity_device(X, topk, 1e-8, torch.device("cpu"), block=64)
+        np.testing.assert_array_equal(dp.numpy(), hp)
+        np.testing.assert_array_equal(di.numpy(), hi)
+        np.testing.assert_allclose(dv.numpy(), hv, rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(dD.numpy(), Sd.sum(axis=1), rtol=1e-5, atol=1e-6)
+    # symmetric, no self loops
+    S = np.zeros((300, 300), dtype=np.float32)
+    S[np.repeat(np.arange(300), np.diff(dp.numpy())), di.numpy()] = dv.numpy()
+    assert np.array_equal(S, S.T) and not S.diagonal().any()

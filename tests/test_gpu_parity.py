@@ -254,3 +254,22 @@ def test_graph_sweep_other_k_against_oracle(k):
     _close(model.V, o.V, what="V")
     _close(model.U, o.U, what="U")
     np.testing.assert_allclose(model.b_i, o.b_i, atol=2e-4, rtol=0)
+
+
+def test_device_graph_build_in_fit():
+    """graph_build='device'  gives the same fit as the reference-style host build when the
+    graph feature has no ties (continuous embedding)."""
+    _cuda()
+    from collaborative_filtering_amd import ALS, ALSConfig, BiasesConfig, CoreConfig, GraphConfig, GraphSimConfig
+    from tests.synth import make_ratings
+    m, n = 400, 300
+    r, c, v = make_ratings(m, n, 9000, seed=77)
+    emb = np.random.default_rng(5).normal(size=(n, 6)).astype(np.float32)
+    cfg = ALSConfig(core=CoreConfig(n_factors=16, n_iters=4, lambda_u=3.0, lambda_v=4.0),
+                    biases=BiasesConfig(2.0, 1.5),
+                    graph=GraphConfig(alpha=0.6, sim=GraphSimConfig(feature_name="emb", topk=12)))
+    a = ALS(cfg, lambda_w={"emb": 4.0}).fit_coo(r, c, v, (m, n), features={"emb": emb}, tol=None, verbose=0)
+    b = ALS(cfg, lambda_w={"emb": 4.0}, graph_build="device").fit_coo(r, c, v, (m, n), features={"emb": emb},
+                                                                     tol=None, verbose=0)
+    np.testing.assert_allclose(a.history["train_rmse"], b.history["train_rmse"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(a.V, b.V, rtol=1e-4, atol=1e-5)
