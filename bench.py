@@ -230,7 +230,13 @@ def main():
     local = local % max(ngpu, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # ALS_FORCE_COLLECTIVES=1: one-rank rehearsal of the sharded path and its RCCL calls on a single GPU
+    dist_on = world > 1 or os.environ.get("ALS_FORCE_COLLECTIVES") == "1"
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -248,7 +254,7 @@ def main():
     if rank == 0:
         csr, csc = gen_ratings(dev, m, n, nnz, seed=1004)
         S = gen_graph(dev, n, seed=2004) if use_graph else None
-    if world > 1:
+    if dist_on:
         def bc(t, dtype, numel):
             if rank != 0:
                 t = torch.empty(numel, dtype=dtype, device=dev)
@@ -284,7 +290,7 @@ def main():
     t_setup = time.perf_counter() - t_setup
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -297,7 +303,7 @@ def main():
         eng.iteration(it, n_total)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -357,7 +363,7 @@ def main():
                       if args.gram == "bf16x3" else "f32"), "data": "synthetic",
             "config": {"workload": f"{args.size}: {m} users x {n} items, {nnz} ratings, k={k}, bias + "
                                    f"graph-Laplacian (alpha=0.5, {0 if S is None else int(S[1].numel())} graph nnz)"
-                                   f" [BASELINE.json configs[3]]",
+                                   + (" [BASELINE.json configs[3]]" if args.size == "cfg4" else ""),
                        "gram": args.gram, "gs_mode": getattr(eng, "gs_mode", None), "gs_levels": (len(eng.sched.offsets) - 1)
                        if eng.use_graph else 0,
                        "parallelism": f"users/items sharded x{world}, all-gather of factor blocks",
@@ -370,7 +376,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(eng)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -18,6 +18,7 @@ signature is unchanged):
 from __future__ import annotations
 
 import logging
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -278,6 +279,9 @@ class _Engine:
             self.world, self.rank = dist.get_world_size(pg), dist.get_rank(pg)
         else:
             self.world, self.rank = 1, 0
+        # `multi`: take the sharded code path with its collectives.  ALS_FORCE_COLLECTIVES=1 takes it on a
+        # one-rank group too, to rehearse the RCCL calls on a single GPU (bench.py / tests only).
+        self.multi = self.world > 1 or (os.environ.get("ALS_FORCE_COLLECTIVES") == "1" and dist.is_initialized())
         k = int(model.n_factors)
         self.k, self.ld = k, layout.padded_k(k)
         self.m, self.n = csr.nrows, csc.nrows
@@ -288,7 +292,7 @@ class _Engine:
 
         # --- shards (contiguous, equal row counts; storage padded to world * per)
         # the user shard is solved in U_CHUNKS sub-ranges whose all-gathers overlap the next sub-range's solve
-        self.u_chunks = self.U_CHUNKS if self.world > 1 else 1
+        self.u_chunks = self.U_CHUNKS if self.multi else 1
         self.u_per, ub = layout.shard_bounds(self.m, self.world, self.u_chunks)
         self.i_per, ib = layout.shard_bounds(self.n, self.world)
         self.ub, self.ue = ub[self.rank]
@@ -372,11 +376,11 @@ class _Engine:
                 D = (csum[self.S_ptr[1:]] - csum[self.S_ptr[:-1]]).to(f32)
             self.diag_extra = torch.zeros(n_pad, dtype=f32, device=device)
             self.diag_extra[: self.n] = np.float32(model.alpha) * D
-            self.gs_mode = gs_mode or ("exact" if self.world == 1 else "block")
+            self.gs_mode = gs_mode or ("block" if self.multi else "exact")
             if self.gs_mode not in ("exact", "block"):
                 raise ValueError(f"unknown gs_mode '{self.gs_mode}'")
             active = counts > 0
-            if self.gs_mode == "block" or self.world == 1:
+            if self.gs_mode == "block" or not self.multi:
                 sched = layout.build_level_schedule(ptr, idx, active, self.ib, self.ie)
             else:
                 sched = layout.build_level_schedule(ptr, idx, active, 0, self.n)
@@ -384,7 +388,7 @@ class _Engine:
             self.sched_items = torch.from_numpy(sched.items).to(device)
             # persistent dataflow sweep (one launch, no level barriers) when the backend has it
             self.gs_dataflow = (hasattr(backend, "gs_dataflow")
-                                and not (self.world > 1 and self.gs_mode == "exact"))
+                                and not (self.multi and self.gs_mode == "exact"))
             if self.gs_dataflow:
                 self.S_idx_wait = torch.from_numpy(layout.wait_edges(ptr, idx, sched.level)).to(device)
                 self.gs_done = torch.zeros(n_pad, dtype=torch.int32, device=device)
@@ -429,13 +433,13 @@ class _Engine:
 
     def _allgather_rows(self, t: torch.Tensor, per: int):
         """In-place all-gather of equal contiguous row shards of `t`."""
-        if self.world == 1:
+        if not self.multi:
             return
         mine = t[self.rank * per:(self.rank + 1) * per].clone()
         dist.all_gather_into_tensor(t.view(-1), mine.view(-1), group=self.pg)
 
     def _allreduce(self, t: torch.Tensor):
-        if self.world > 1:
+        if self.multi:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
 
     def _check_status(self):
@@ -535,7 +539,7 @@ class _Engine:
     def _gs_sweep(self):
         md = self.model
         off = self.sched.offsets
-        exact_multi = self.world > 1 and self.gs_mode == "exact"
+        exact_multi = self.multi and self.gs_mode == "exact"
         kw = dict(k=self.k, ld=self.ld, S_ptr=self.S_ptr, S_idx=self.S_idx, S_val=self.S_val,
                   alpha=md.alpha, factor=self.factor, rhs=self.rhs_out, colsum=self.colsum_out,
                   sumr=self.sumr, indptr=self.csc.indptr, lam_b=md.lambda_bi, lam_b_row=None,
@@ -619,7 +623,7 @@ class _Engine:
             A_full, B_full = self.be.w_accumulate(k=k, ld=ld, item_begin=self.ib, item_end=self.ie,
                                                   gram=self.gram, X=self.Xcat, H=self.H, feat_index=fi,
                                                   feat_col0=int(self.feat_off_host[fi]), feat_d=d)
-            if self.world > 1:
+            if self.multi:
                 self._allreduce(A_full)
                 self._allreduce(B_full)
             sel = (torch.arange(d, device=self.dev)[:, None] * ld + pk[None, :]).reshape(-1)   # (a, c) -> a*ld + perm(c)
@@ -669,7 +673,7 @@ class _Engine:
             Pm = (X[:, :, None] * X[:, None, :]).reshape(X.shape[0], d * d)
             T = Pm.transpose(0, 1) @ Gflat                                  # [d*d, k*k]
             A = T.reshape(d, d, k, k).permute(0, 2, 1, 3).reshape(d * k, d * k).contiguous()
-            if self.world > 1:
+            if self.multi:
                 self._allreduce(A)
                 self._allreduce(B)
             lam = float(md.lambda_w.get(f, 0.0))

@@ -127,3 +127,22 @@ def test_fused_statistics_closed_form_on_cpu():
     assert a._eng.fused_stats and not b._eng.fused_stats
     np.testing.assert_allclose(a.history["train_rmse"], b.history["train_rmse"], rtol=1e-6)
     np.testing.assert_allclose(a.V, b.V, rtol=1e-5, atol=1e-7)
+
+
+def _forced_worker(rank, world, port, name, gs_mode, outdir):
+    os.environ["ALS_FORCE_COLLECTIVES"] = "1"
+    _worker(rank, world, port, name, gs_mode, outdir)
+
+
+@pytest.mark.parametrize("gs_mode", ["block", "exact"])
+def test_forced_collectives_on_one_rank(gs_mode):
+    """ALS_FORCE_COLLECTIVES=1 takes the sharded code path (chunked U-step with async all-gathers,
+    per-level exchange in exact mode) on a one-rank group - the rehearsal mode `bench.py` uses to
+    exercise the RCCL calls on a single GPU.  Results must equal the plain single-process run."""
+    g, ref = _single("g5_graph_a0.5")
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_forced_worker, args=(1, _free_port(), "g5_graph_a0.5", gs_mode, d), nprocs=1, join=True)
+        out = np.load(os.path.join(d, "rank0.npz"))
+    np.testing.assert_array_equal(out["U"], ref.U)
+    np.testing.assert_array_equal(out["V"], ref.V)
+    np.testing.assert_array_equal(out["rmse"], ref.history["train_rmse"])
