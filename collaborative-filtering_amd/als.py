@@ -602,8 +602,8 @@ class _Engine:
         (rhs, column sums), so no extra pass over the ratings is needed.  The
         Jacobi-across-features quirk (:474-489) and the lambda=0-for-missing
         quirk (:497) are kept.  A_f / b_f come from the HIP kernels of
-        w_step.hip (als_w_normal_equations) in fp64; only the dense (d k)^2
-        Cholesky solve is a library call.
+        w_step.hip (als_w_normal_equations) in fp64 and are solved by the blocked
+        fp64 Cholesky of spd_solve.hip (als_spd_solve_f64).
         """
         if not hasattr(self.be, "w_accumulate"):
             return self._w_step_host_algebra(b_i_old)        # test stand-in backends only
@@ -614,6 +614,7 @@ class _Engine:
             offs = np.concatenate([[0], np.cumsum(self.feat_dims)]).astype(np.int32)
             self.feat_off_host = offs
             self.feat_off = torch.from_numpy(offs).to(self.dev)
+            self.w_status = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.be.w_item_vectors(k=k, ld=ld, item_begin=self.ib, item_end=self.ie, gram=self.gram,
                                rhs=self.rhs_out, colsum=self.colsum_out, V=self.V, b_new=self.b_i,
                                b_old=b_i_old, X=self.Xcat, feat_off=self.feat_off, W=self.Wcat, H=self.H)
@@ -629,11 +630,11 @@ class _Engine:
             sel = (torch.arange(d, device=self.dev)[:, None] * ld + pk[None, :]).reshape(-1)   # (a, c) -> a*ld + perm(c)
             A = A_full[sel][:, sel].contiguous()
             B = B_full[sel]
-            A.diagonal().add_(float(md.lambda_w.get(f, 0.0)) + EPS)
-            L, info = torch.linalg.cholesky_ex(A)
-            if int(info.item()) != 0:
+            x = self.be.spd_solve(A, B, float(md.lambda_w.get(f, 0.0)) + EPS, self.w_status)
+            bad = int(self.w_status.item())
+            if bad:
                 raise np.linalg.LinAlgError(f"W-step normal equations of feature '{f}' are not positive definite")
-            newW[f] = torch.cholesky_solve(B.reshape(d * k, 1), L).reshape(d, k)
+            newW[f] = x.reshape(d, k)
         self.W64.update(newW)
         self._sync_wcat()
 

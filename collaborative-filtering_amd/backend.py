@@ -37,6 +37,7 @@ class HipBackend:
         self._sumsq_partials = torch.empty(self.lib.als_sumsq_partials(), dtype=torch.float64,
                                            device=device)
         self._stats_partials: Optional[torch.Tensor] = None
+        self._spd_ws: Optional[torch.Tensor] = None
         self.ablate = int(__import__('os').environ.get('ALS_ABLATE', '0'))   # diagnostics only
 
     # -- helpers -------------------------------------------------------------
@@ -144,6 +145,20 @@ class HipBackend:
         p.partA, p.partB, p.A_out, p.B_out = _p(partA), _p(partB), _p(A), _p(B)
         self._check(self.lib.als_w_normal_equations(C.byref(p), self._stream()), "als_w_normal_equations(1)")
         return A, B
+
+    def spd_solve(self, A: torch.Tensor, b: torch.Tensor, diag_add: float, status: torch.Tensor) -> torch.Tensor:
+        """x = (A + diag_add I)^-1 b, dense fp64 Cholesky (scripts/als.py:497-500).  status: device int32[1]."""
+        N = A.shape[0]
+        assert A.dtype == torch.float64 and A.is_contiguous() and A.shape == (N, N) and b.numel() == N
+        nbytes = int(self.lib.als_spd_solve_workspace_bytes(N))
+        if nbytes == 0:
+            raise ValueError(f"W-step system of order {N} exceeds ALS_SPD_MAX_N")
+        if self._spd_ws is None or self._spd_ws.numel() < nbytes:
+            self._spd_ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        x = torch.empty(N, dtype=torch.float64, device=self.device)
+        self._check(self.lib.als_spd_solve_f64(N, _p(A), N, _p(b), float(diag_add), _p(x), _p(self._spd_ws),
+                                               _p(status), self._stream()), "als_spd_solve_f64")
+        return x
 
     # -- K6 ------------------------------------------------------------------
     def residual_stats(self, *, k, ld, side, U, Z, b_u, b_i, mu, tasks, out):

@@ -27,6 +27,7 @@
 #ifndef ALS_HIP_H
 #define ALS_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -241,6 +242,20 @@ typedef struct als_w_params {
 } als_w_params;
 
 int als_w_normal_equations(const als_w_params* p, void* stream);
+
+/* -------------------------------------------------------------------------
+ * als_spd_solve_f64: x = (A + diag_add I)^-1 b by a dense fp64 Cholesky factorisation -
+ * the reference's `cholesky_solve(A, b)` on the W-step's (d k) x (d k) normal equations
+ * (scripts/als.py:497-500; scripts/helpers.py cholesky_solve).
+ * A: [N][lda] row-major fp64, symmetric (both triangles valid), not modified.  b, x: [N] (may alias).
+ * workspace: als_spd_solve_workspace_bytes(N) bytes of device memory (0 = N out of range).
+ * status (device int32): 0 ok; p > 0: pivot p-1 was not positive (not SPD, x is then meaningless).
+ * Enqueues 2 ceil(N/64) + 2 small kernels on `stream`.
+ * ------------------------------------------------------------------------- */
+#define ALS_SPD_MAX_N 8128
+size_t als_spd_solve_workspace_bytes(int64_t N);
+int als_spd_solve_f64(int64_t N, const double* A, int64_t lda, const double* b, double diag_add,
+                      double* x, void* workspace, int32_t* status, void* stream);
 
 /* out[0] = sum_i x[2i], out[1] = sum_i x[2i+1] in fp64 (reduction of stat_out).
  * partials: scratch of 2*als_sumsq_partials() doubles. */

@@ -21,7 +21,7 @@ def lib():
 def test_header_symbols_are_exported(lib):
     from collaborative_filtering_amd import _hip
     text = open(os.path.join(ROOT, "include", "als_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|int64_t)\s+(als_\w+)\s*\(", text, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|size_t)\s+(als_\w+)\s*\(", text, flags=re.M))
     assert declared == set(_hip.EXPORTS), declared ^ set(_hip.EXPORTS)
     for name in declared:
         assert hasattr(lib, name)

@@ -236,3 +236,49 @@ def test_bad_arguments_are_rejected():
     p.k, p.ld = 64, 48                       # ld does not match k
     assert lib.als_row_solve(C.byref(p), None) == -1
     assert lib.als_row_solve(None, None) == -1
+    assert lib.als_spd_solve_workspace_bytes(0) == 0 and lib.als_spd_solve_workspace_bytes(8129) == 0
+    assert lib.als_spd_solve_f64(0, None, 0, None, 0.0, None, None, None, None) == -1
+
+
+def _spd_system(N, seed, cond=1e4):
+    rng = np.random.default_rng(seed)
+    B = rng.normal(size=(N, max(N // 2, 1)))
+    A = B @ B.T + np.diag(rng.uniform(1.0 / cond, 1.0, size=N)) * N       # SPD, moderately conditioned
+    A = 0.5 * (A + A.T)
+    return A, rng.normal(size=N)
+
+
+@pytest.mark.parametrize("N", [1, 7, 50, 64, 65, 128, 200, 950, 1216, 2432])
+def test_spd_solve_against_numpy(N):
+    """als_spd_solve_f64 (the W-step's cholesky_solve, scripts/als.py:497-500) against numpy fp64:
+    relative error of x at fp64 level scaled by the condition number, residual at rounding level,
+    bitwise reproducible, inputs untouched."""
+    torch, layout, side_dev, tasks_dev, be, dev = _env()
+    A, b = _spd_system(N, seed=N)
+    lam = 0.75
+    ref = np.linalg.solve(A + lam * np.eye(N), b)
+    At, bt = torch.from_numpy(A).to(dev), torch.from_numpy(b).to(dev)
+    status = torch.full((1,), 7, dtype=torch.int32, device=dev)
+    x1 = be.spd_solve(At, bt, lam, status)
+    assert int(status.item()) == 0
+    x2 = be.spd_solve(At, bt, lam, status)
+    assert torch.equal(x1, x2)
+    assert np.array_equal(At.cpu().numpy(), A) and np.array_equal(bt.cpu().numpy(), b)
+    x = x1.cpu().numpy()
+    cond = np.linalg.cond(A + lam * np.eye(N))
+    assert np.linalg.norm(x - ref) <= 50 * cond * np.finfo(np.float64).eps * np.linalg.norm(ref)
+    res = (A + lam * np.eye(N)) @ x - b
+    assert np.linalg.norm(res) <= 1e-12 * (np.linalg.norm(A) * np.linalg.norm(x) + np.linalg.norm(b))
+
+
+def test_spd_solve_reports_indefinite_matrices():
+    torch, layout, side_dev, tasks_dev, be, dev = _env()
+    N = 130
+    A, b = _spd_system(N, seed=3)
+    A[100, 100] = -5.0                                   # pivot 100 (or an earlier one) turns non-positive
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    be.spd_solve(torch.from_numpy(A).to(dev), torch.from_numpy(b).to(dev), 0.0, status)
+    assert 1 <= int(status.item()) <= 101
+    A2 = np.zeros((3, 3))
+    be.spd_solve(torch.from_numpy(A2).to(dev), torch.zeros(3, dtype=torch.float64, device=dev), 0.0, status)
+    assert int(status.item()) == 1
