@@ -618,7 +618,6 @@ class _Engine:
         self.be.w_item_vectors(k=k, ld=ld, item_begin=self.ib, item_end=self.ie, gram=self.gram,
                                rhs=self.rhs_out, colsum=self.colsum_out, V=self.V, b_new=self.b_i,
                                b_old=b_i_old, X=self.Xcat, feat_off=self.feat_off, W=self.Wcat, H=self.H)
-        pk = self.perm[:k]                          # perm position of storage column c
         newW = {}
         for fi, (f, d) in enumerate(zip(self.feat_names, self.feat_dims)):
             A_full, B_full = self.be.w_accumulate(k=k, ld=ld, item_begin=self.ib, item_end=self.ie,
@@ -627,10 +626,7 @@ class _Engine:
             if self.multi:
                 self._allreduce(A_full)
                 self._allreduce(B_full)
-            sel = (torch.arange(d, device=self.dev)[:, None] * ld + pk[None, :]).reshape(-1)   # (a, c) -> a*ld + perm(c)
-            A = A_full[sel][:, sel].contiguous()
-            B = B_full[sel]
-            x = self.be.spd_solve(A, B, float(md.lambda_w.get(f, 0.0)) + EPS, self.w_status)
+            x = self.be.spd_solve(A_full, B_full, float(md.lambda_w.get(f, 0.0)) + EPS, self.w_status)
             bad = int(self.w_status.item())
             if bad:
                 raise np.linalg.LinAlgError(f"W-step normal equations of feature '{f}' are not positive definite")

@@ -129,14 +129,16 @@ class HipBackend:
         self._check(self.lib.als_w_normal_equations(C.byref(p), self._stream()), "als_w_normal_equations(0)")
 
     def w_accumulate(self, *, k, ld, item_begin, item_end, gram, X, H, feat_index, feat_col0, feat_d):
-        """(A [(d ld)^2], B [d ld]) fp64 for one feature over items [item_begin, item_end)."""
+        """(A [(d k)^2], B [d k]) fp64, storage order, for one feature over items [item_begin, item_end)."""
         npairs = feat_d * (feat_d + 1) // 2
-        nchunks = max(1, min(64, -(-1024 // npairs)))
+        nit = max(int(item_end) - int(item_begin), 1)
+        nchunks = max(1, min(64, 4096 // npairs, -(-nit // 256)))
+        kb = ld // 16
         f64 = torch.float64
-        partA = torch.empty(npairs * nchunks * ld * ld, dtype=f64, device=self.device)
+        partA = torch.empty(npairs * nchunks * (kb * (kb + 1) // 2) * 256, dtype=f64, device=self.device)
         partB = torch.empty(feat_d * nchunks * ld, dtype=f64, device=self.device)
-        A = torch.empty(feat_d * ld, feat_d * ld, dtype=f64, device=self.device)
-        B = torch.empty(feat_d * ld, dtype=f64, device=self.device)
+        A = torch.empty(feat_d * k, feat_d * k, dtype=f64, device=self.device)
+        B = torch.empty(feat_d * k, dtype=f64, device=self.device)
         p = _hip.WParams()
         p.k, p.ld, p.phase = k, ld, 1
         p.item_begin, p.item_end = int(item_begin), int(item_end)

@@ -11,9 +11,9 @@
 // (als_device.hpp); accumulation is fp64.
 //
 //   k_w_item_vectors   one wave per item: h_{f,i} for every feature (perm space, fp32)
-//   k_w_accumulate     one workgroup per (feature-column pair a <= a', item chunk): partial 64x64..160x160
-//                      blocks sum_i x_ia x_ia' G_i and (a == a') partial b rows, skipping zero x
-//   k_w_reduce         fixed-order sum over the chunks, mirrored into the full (d*ld)^2 matrix
+//   k_w_accumulate     one workgroup per (feature-column pair a <= a', item chunk): partial lower blocks of
+//                      sum_i x_ia x_ia' G_i and (a == a') partial b rows; contributing items compacted per tile
+//   k_w_reduce         fixed-order sum over the chunks, written into the compact (d*k)^2 system (storage order)
 #include "als_device.hpp"
 #include "als_hip.h"
 
@@ -85,65 +85,139 @@ void k_w_item_vectors(int k, int64_t i0, int64_t i1, const float* __restrict__ g
     }
 }
 
-// grid: (npairs, nchunks); block 256.  Thread t owns row r = t >> 2 ... of the KP x KP block in strips.
+// lower 16x16 block q of the KB x KB block grid (row-major over I >= J): q -> (I, J)
+__device__ __forceinline__ void lower_block(int q, int& I, int& J) {
+    I = 0;
+    while (q > I) { q -= I + 1; ++I; }
+    J = q;
+}
+
+// grid: (npairs, nchunks); block 256.  One workgroup sums w_i G_i (w_i = x_ia x_ia') over the items of
+// its chunk for one feature-column pair a <= a', lower 16x16 blocks only: thread t owns element
+// (t >> 4, t & 15) of every lower block (NACC fp64 accumulators).  The chunk is walked in tiles of 256
+// items: the tile's contributing items (w != 0) are compacted, in item order, into an LDS list, and the
+// list is consumed four items at a time so that 4 NACC independent loads are in flight per thread (a
+// serial `if (w == 0) continue` loop pays one dependent-load latency per item).  Fixed summation order.
 template <int KB>
 __global__ __launch_bounds__(256)
 void k_w_accumulate(int64_t i0, int64_t i1, int nchunks, const float* __restrict__ gram, int D, int foff, int d,
                     const float* __restrict__ X, const float* __restrict__ Hf, double* __restrict__ partA,
                     double* __restrict__ partB) {
-    constexpr int KP = KCfg<KB>::KP;
-    constexpr int EPT = KP * KP / 256;             // elements per thread (16 at KP = 64)
-    // pair index -> (a, a2), a <= a2
+    constexpr int KP = KCfg<KB>::KP, NACC = KCfg<KB>::NACC;
+    __shared__ int l_item[256];
+    __shared__ float l_w[256], l_xa[256];
+    __shared__ int l_cnt[4];
     int pair = blockIdx.x, a = 0;
     while (pair >= d - a) { pair -= d - a; ++a; }
     const int a2 = a + pair;
     const int chunk = blockIdx.y;
     const int64_t per = (i1 - i0 + nchunks - 1) / nchunks;
     const int64_t cb = i0 + chunk * per, ce = min(i1, cb + per);
-    double acc[EPT];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int rr = t >> 4, cc = t & 15;
+    int off[NACC], offT[NACC];                     // element offsets inside G_i; offT: canonical (lower) twin
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) acc[e] = 0.0;
-    double accb = 0.0;                             // thread t < KP: b row entry (only when a == a2)
-    const int t = threadIdx.x;
-    for (int64_t i = cb; i < ce; ++i) {
-        const float xa = X[i * D + foff + a], xb = X[i * D + foff + a2];
-        const float w = xa * xb;
-        if (w == 0.f) continue;                    // block-uniform: every thread reads the same x
-        const float* G = gram + i * KP * KP;
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const int idx = e * 256 + t;           // consecutive threads -> consecutive columns
-            acc[e] += (double)w * (double)gsym(G, KP, idx / KP, idx % KP);
-        }
-        if (a == a2 && t < KP) accb += (double)xa * (double)Hf[i * KP + t];
+    for (int q = 0; q < NACC; ++q) {
+        int I, J;
+        lower_block(q, I, J);
+        off[q] = (16 * I + rr) * KP + 16 * J + cc;
+        offT[q] = (I == J && rr < cc) ? (16 * I + cc) * KP + 16 * J + rr : off[q];
     }
-    double* pA = partA + ((int64_t)blockIdx.x * nchunks + chunk) * KP * KP;
+    double acc[NACC];
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) pA[e * 256 + t] = acc[e];
-    if (a == a2 && t < KP) partB[((int64_t)a * nchunks + chunk) * KP + t] = accb;
+    for (int q = 0; q < NACC; ++q) acc[q] = 0.0;
+    double accb = 0.0;                             // thread t < KP: b row entry (only when a == a2)
+    const bool want_b = (a == a2) && t < KP;
+    for (int64_t tile = cb; tile < ce; tile += 256) {
+        const int64_t i = tile + t;
+        float xa = 0.f, w = 0.f;
+        if (i < ce) {
+            xa = X[i * D + foff + a];
+            w = xa * X[i * D + foff + a2];
+        }
+        const unsigned long long m = __ballot(w != 0.f);
+        if (lane == 0) l_cnt[wv] = __popcll(m);
+        __syncthreads();
+        int base = 0, total = 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { base += (v < wv) ? l_cnt[v] : 0; total += l_cnt[v]; }
+        if (w != 0.f) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            l_item[pos] = (int)(i - tile);
+            l_w[pos] = w;
+            l_xa[pos] = xa;
+        }
+        __syncthreads();
+        int n = 0;
+        for (; n + 4 <= total; n += 4) {
+            float g[4][NACC], h[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t it = tile + l_item[n + u];
+                const float* G = gram + it * KP * KP;
+#pragma unroll
+                for (int q = 0; q < NACC; ++q) g[u][q] = G[offT[q]];
+                h[u] = want_b ? Hf[it * KP + t] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double w64 = (double)l_w[n + u];
+#pragma unroll
+                for (int q = 0; q < NACC; ++q) acc[q] += w64 * (double)g[u][q];
+                accb += (double)l_xa[n + u] * (double)h[u];
+            }
+        }
+        for (; n < total; ++n) {
+            const int64_t it = tile + l_item[n];
+            const float* G = gram + it * KP * KP;
+            const double w64 = (double)l_w[n];
+#pragma unroll
+            for (int q = 0; q < NACC; ++q) acc[q] += w64 * (double)G[offT[q]];
+            if (want_b) accb += (double)l_xa[n] * (double)Hf[it * KP + t];
+        }
+        __syncthreads();
+    }
+    double* pA = partA + ((int64_t)blockIdx.x * nchunks + chunk) * (NACC * 256);
+#pragma unroll
+    for (int q = 0; q < NACC; ++q) pA[q * 256 + t] = acc[q];
+    if (want_b) partB[((int64_t)a * nchunks + chunk) * KP + t] = accb;
 }
 
+// Fixed-order sum over the chunks, written straight into the compact system of the feature:
+// A [(d k)][(d k)], row/col index a k + storage column, B [d k]; padded perm positions are dropped.
+// Block (a, a') of A is symmetric itself (G_i is), and block (a', a) is its transpose: every lower
+// element lands in up to four places with the same value (bitwise symmetric A).
 template <int KB>
 __global__ __launch_bounds__(256)
-void k_w_reduce(int nchunks, int d, const double* __restrict__ partA, const double* __restrict__ partB,
+void k_w_reduce(int k, int nchunks, int d, const double* __restrict__ partA, const double* __restrict__ partB,
                 double* __restrict__ A, double* __restrict__ B) {
-    constexpr int KP = KCfg<KB>::KP;
+    constexpr int KP = KCfg<KB>::KP, NACC = KCfg<KB>::NACC;
     int pair = blockIdx.x, a = 0;
     while (pair >= d - a) { pair -= d - a; ++a; }
     const int a2 = a + pair;
-    const int64_t N = (int64_t)d * KP;
-    for (int idx = threadIdx.x; idx < KP * KP; idx += 256) {
+    const int64_t N = (int64_t)d * k;
+    const int t = threadIdx.x, rr = t >> 4, cc = t & 15;
+    for (int q = 0; q < NACC; ++q) {
         double s = 0.0;
-        for (int c = 0; c < nchunks; ++c) s += partA[((int64_t)blockIdx.x * nchunks + c) * KP * KP + idx];
-        const int r = idx / KP, cc = idx % KP;
-        A[((int64_t)a * KP + r) * N + (int64_t)a2 * KP + cc] = s;
-        A[((int64_t)a2 * KP + cc) * N + (int64_t)a * KP + r] = s;       // each block is symmetric itself
+        for (int c = 0; c < nchunks; ++c) s += partA[((int64_t)blockIdx.x * nchunks + c) * (NACC * 256) + q * 256 + t];
+        int I, J;
+        lower_block(q, I, J);
+        if (I == J && rr < cc) continue;           // the canonical twin (cc, rr) of this thread's element writes it
+        const int r = perm_to_col<KB>(16 * I + rr), c2 = perm_to_col<KB>(16 * J + cc);
+        if (r >= k || c2 >= k) continue;
+        const int64_t ra = (int64_t)a * k, rb = (int64_t)a2 * k;
+        A[(ra + r) * N + rb + c2] = s;
+        A[(ra + c2) * N + rb + r] = s;
+        A[(rb + c2) * N + ra + r] = s;
+        A[(rb + r) * N + ra + c2] = s;
     }
     if (a == a2)
-        for (int tt = threadIdx.x; tt < KP; tt += 256) {
+        for (int tt = t; tt < KP; tt += 256) {
+            const int col = perm_to_col<KB>(tt);
+            if (col >= k) continue;
             double s = 0.0;
             for (int c = 0; c < nchunks; ++c) s += partB[((int64_t)a * nchunks + c) * KP + tt];
-            B[(int64_t)a * KP + tt] = s;
+            B[(int64_t)a * k + col] = s;
         }
 }
 
@@ -161,7 +235,7 @@ int launch_w(const als_w_params* p, hipStream_t st) {
         hipLaunchKernelGGL(k_w_accumulate<KB>, dim3(npairs, p->nchunks), dim3(256), 0, st, p->item_begin,
                            p->item_end, p->nchunks, p->gram, p->D, p->feat_col0, d, p->X,
                            p->H + (int64_t)p->feat_index * p->nrows_h * KP, p->partA, p->partB);
-        hipLaunchKernelGGL(k_w_reduce<KB>, dim3(npairs), dim3(256), 0, st, p->nchunks, d, p->partA, p->partB,
+        hipLaunchKernelGGL(k_w_reduce<KB>, dim3(npairs), dim3(256), 0, st, p->k, p->nchunks, d, p->partA, p->partB,
                            p->A_out, p->B_out);
     }
     return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;

@@ -211,9 +211,10 @@ int als_residual_stats(int k, int ld, const int64_t* indptr, const int32_t* indi
  *   phase 0: per-item vectors h_{f,i} = g_i + G_i xw_{f,i} for all features (H, perm space),
  *            from the V-step by-products gram/rhs/colsum (als_row_solve), the new and old item
  *            bias, V and the OLD projections W (Jacobi across features, as the reference).
- *   phase 1: for ONE feature (columns feat_col0 .. +feat_d of X): A_out [(d*ld)^2] =
- *            sum_i (x_i x_i^T) (x) G_i and B_out [d*ld] = sum_i x_i (x) h_{f,i}, fp64, perm space,
- *            padded positions included (the caller selects the k real ones and adds lambda).
+ *   phase 1: for ONE feature (columns feat_col0 .. +feat_d of X): A_out [(d*k)^2] =
+ *            sum_i (x_i x_i^T) (x) G_i and B_out [d*k] = sum_i x_i (x) h_{f,i}, fp64, index
+ *            a*k + c with c the factor column in storage order (the reference's vec layout,
+ *            scripts/als.py:494); A_out is bitwise symmetric; the caller adds lambda.
  * Items [item_begin, item_end) only (a rank's shard); A/B are then all-reduced by the caller.
  * ------------------------------------------------------------------------- */
 typedef struct als_w_params {
@@ -235,10 +236,10 @@ typedef struct als_w_params {
     float* H;                      /* [nfeat][nrows_h][ld] (phase 0 writes, phase 1 reads) */
     int64_t nrows_h;
     int32_t feat_index, feat_col0, feat_d, nchunks;   /* phase 1 */
-    double* partA;                 /* scratch: d(d+1)/2 * nchunks * ld*ld doubles */
+    double* partA;                 /* scratch: d(d+1)/2 * nchunks * (ld/16)(ld/16+1)/2 * 256 doubles */
     double* partB;                 /* scratch: d * nchunks * ld doubles */
-    double* A_out;                 /* [(d*ld)][(d*ld)] */
-    double* B_out;                 /* [d*ld] */
+    double* A_out;                 /* [(d*k)][(d*k)] */
+    double* B_out;                 /* [d*k] */
 } als_w_params;
 
 int als_w_normal_equations(const als_w_params* p, void* stream);
