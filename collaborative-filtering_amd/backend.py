@@ -132,7 +132,7 @@ class HipBackend:
         """(A [(d k)^2], B [d k]) fp64, storage order, for one feature over items [item_begin, item_end)."""
         npairs = feat_d * (feat_d + 1) // 2
         nit = max(int(item_end) - int(item_begin), 1)
-        nchunks = max(1, min(64, 4096 // npairs, -(-nit // 256)))
+        nchunks = max(1, min(512, 4096 // npairs, -(-nit // 64)))
         kb = ld // 16
         f64 = torch.float64
         partA = torch.empty(npairs * nchunks * (kb * (kb + 1) // 2) * 256, dtype=f64, device=self.device)

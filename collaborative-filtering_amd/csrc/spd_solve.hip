@@ -9,8 +9,9 @@
 //                    y^T = (L^-1 b)^T in that row, i.e. the forward solve is free.
 //   k_spd_panel      one workgroup per row tile r > j: the 64x64 diagonal block and the tile are
 //                    eliminated together, 4 rows x 8 interleaved columns per thread in registers,
-//                    one LDS round trip per pivot (the diagonal block is eliminated redundantly by
-//                    every workgroup, so nothing separates it from the triangular solve).
+//                    one LDS round trip per pivot, the bulk of a pivot's rank-1 update deferred
+//                    behind the publication of the next pivot (the diagonal block is eliminated
+//                    redundantly by every workgroup, so nothing separates it from the triangular solve).
 //   k_spd_update     one workgroup per trailing tile (r, c): C -= L(r,j) L(c,j)^T on the fp64
 //                    matrix cores (v_mfma_f64_16x16x4_f64), operands straight from global memory.
 //   k_spd_backsolve  L^T x = y by one workgroup: in-wave 64x64 triangular solves (readlane
@@ -79,60 +80,89 @@ __device__ __forceinline__ void publish_pivot(double p, double* dst, bool report
 }
 
 struct PanelCtx { double* cbuf; int32_t* status; int g, rg, row0, j; bool write_diag; };
+struct StepRegs { double m[4]; double cv[8]; };      // multipliers and column values of one pivot
 
-// one pivot of the panel; t is a template parameter so that every index into x[][] is static
-// (a 64-trip `#pragma unroll` exceeds the unroller's budget and would push x[][] into scratch)
+// One pivot of the panel, split in two so that the next pivot can be published as early as possible:
+//   step_head<t>: after the barrier read 1/p, 1/sqrt(p), this thread's 4 row entries and its <= 8 column
+//                 values; finalise column t; update ONLY column t + 1 and publish it with its pivot.
+//   step_tail<t>: the remaining rank-1 updates of pivot t.  It is issued after the NEXT barrier, between
+//                 the LDS reads of pivot t + 1 and their first use, so it fills that latency instead of
+//                 delaying the publication.
+// t is a template parameter so that every index into x[][] is static (a 64-trip `#pragma unroll`
+// exceeds the unroller's budget and would push x[][] into scratch).
 template <int t>
-__device__ __forceinline__ void panel_step(double (&x)[4][8], const PanelCtx& cx) {
+__device__ __forceinline__ void step_reads(const PanelCtx& cx, StepRegs& R, double& dv, double (&rv)[4]) {
     constexpr int CB = 2 * NB + 2;
-    const int g = cx.g, row0 = cx.row0;
-    __syncthreads();
+    constexpr int ct = t >> 3;
     const double* cb = cx.cbuf + (t & 1) * CB;
-    constexpr int gt = t & 7, ct = t >> 3;
-    const double ip = cb[2 * NB], dv = cb[2 * NB + 1];
-    const f64x2 r01 = *reinterpret_cast<const f64x2*>(cb + row0);
-    const f64x2 r23 = *reinterpret_cast<const f64x2*>(cb + row0 + 2);
-    const double rv[4] = {r01.x, r01.y, r23.x, r23.y};
-    double m[4];
+    const double ip = cb[2 * NB];
+    dv = cb[2 * NB + 1];
+    const f64x2 r01 = *reinterpret_cast<const f64x2*>(cb + cx.row0);
+    const f64x2 r23 = *reinterpret_cast<const f64x2*>(cb + cx.row0 + 2);
+    rv[0] = r01.x; rv[1] = r01.y; rv[2] = r23.x; rv[3] = r23.y;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) m[i] = rv[i] * ip;
+    for (int ci = ct; ci < 8; ++ci) R.cv[ci] = cb[cx.g + 8 * ci];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) R.m[i] = -(rv[i] * ip);
+}
+
+template <int t>
+__device__ __forceinline__ void step_head(double (&x)[4][8], const PanelCtx& cx, const StepRegs& R, double dv,
+                                          const double (&rv)[4]) {
+    constexpr int CB = 2 * NB + 2;
+    constexpr int gt = t & 7, ct = t >> 3;
+    const int g = cx.g;
     if (g == gt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[i][ct] = rv[i] * dv;          // final L[row][t]
     }
-    // columns c = g + 8 ci > t: ci > ct always, ci == ct only for g > gt
-    if (g > gt) {
-        const double cv = cb[t - gt + g];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) x[i][ct] = fma(-m[i], cv, x[i][ct]);
-    }
-#pragma unroll
-    for (int ci = ct + 1; ci < 8; ++ci) {
-        const double cv = cb[g + 8 * ci];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) x[i][ci] = fma(-m[i], cv, x[i][ci]);
-    }
-    // pin this pivot's updates here: without it the compiler sinks the FMAs of late columns across many
-    // barriers and keeps the LDS operands of all of them alive (hundreds of spilled registers)
-#pragma unroll
-    for (int ci = ct; ci < 8; ++ci)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(x[i][ci]));
     if constexpr (t + 1 < NB) {
         constexpr int g1 = (t + 1) & 7, c1 = (t + 1) >> 3;
         double* nb = cx.cbuf + ((t + 1) & 1) * CB;
         if (g == g1) {
-            *reinterpret_cast<f64x2*>(nb + row0) = f64x2{x[0][c1], x[1][c1]};
-            *reinterpret_cast<f64x2*>(nb + row0 + 2) = f64x2{x[2][c1], x[3][c1]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i][c1] = fma(R.m[i], R.cv[c1], x[i][c1]);
+            *reinterpret_cast<f64x2*>(nb + cx.row0) = f64x2{x[0][c1], x[1][c1]};
+            *reinterpret_cast<f64x2*>(nb + cx.row0 + 2) = f64x2{x[2][c1], x[3][c1]};
             if (cx.rg == (t + 1) / 4)
                 publish_pivot(x[(t + 1) & 3][c1], nb + 2 * NB, cx.write_diag, cx.status, cx.j * NB + t + 1);
         }
     }
 }
+
 template <int t>
-__device__ __forceinline__ void panel_steps(double (&x)[4][8], const PanelCtx& cx) {
-    panel_step<t>(x, cx);
-    if constexpr (t + 1 < NB) panel_steps<t + 1>(x, cx);
+__device__ __forceinline__ void step_tail(double (&x)[4][8], const PanelCtx& cx, const StepRegs& R) {
+    constexpr int gt = t & 7, ct = t >> 3;
+    constexpr int g1 = (t + 1) & 7, c1 = (t + 1) >> 3;
+    const int g = cx.g;
+    // columns c = g + 8 ci > t, minus column t + 1 (done in step_head): ci > ct always, ci == ct for g > gt
+#pragma unroll
+    for (int ci = ct; ci < 8; ++ci) {
+        bool on = (ci > ct) || (g > gt);
+        if (ci == c1) on = on && (g != g1);
+        if (on) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i][ci] = fma(R.m[i], R.cv[ci], x[i][ci]);
+        }
+    }
+    // pin the updates here: otherwise the compiler sinks the FMAs of late columns across many barriers and
+    // keeps the operands of all of them alive (hundreds of spilled registers)
+#pragma unroll
+    for (int ci = ct; ci < 8; ++ci)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(x[i][ci]));
+}
+
+template <int t>
+__device__ __forceinline__ void panel_steps(double (&x)[4][8], const PanelCtx& cx, const StepRegs& prev) {
+    __syncthreads();
+    StepRegs R;
+    double dv, rv[4];
+    step_reads<t>(cx, R, dv, rv);
+    if constexpr (t > 0) step_tail<t - 1>(x, cx, prev);
+    step_head<t>(x, cx, R, dv, rv);
+    if constexpr (t + 1 < NB) panel_steps<t + 1>(x, cx, R);
+    else step_tail<t>(x, cx, R);
 }
 
 __device__ __forceinline__ void panel(double* __restrict__ M, int64_t ld, int j, int r, bool write_diag,
@@ -155,7 +185,8 @@ __device__ __forceinline__ void panel(double* __restrict__ M, int64_t ld, int j,
         if (rg == 0) publish_pivot(x[0][0], cbuf + 2 * NB, write_diag, status, j * NB);
     }
     PanelCtx cx{cbuf, status, g, rg, row0, j, write_diag};
-    panel_steps<0>(x, cx);
+    StepRegs none{};
+    panel_steps<0>(x, cx, none);
     if (!diag) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -217,6 +248,7 @@ void k_spd_update(int T, int64_t ld, double* __restrict__ M, int j) {
 }
 
 // L^T x = y; y is row NP of M.  One workgroup of 512 threads; s (the running right-hand side) in LDS.
+// Bound by what one CU can stream (the strictly lower triangle once, ~60 GB/s): ~160 us at N = 1216.
 __global__ __launch_bounds__(512)
 void k_spd_backsolve(int T, int64_t N, int64_t ld, const double* __restrict__ M, const double* __restrict__ Ld,
                      double* __restrict__ x_out) {

@@ -42,6 +42,21 @@ __device__ __forceinline__ void gsym_matvec(const float* __restrict__ G, const i
     }
 }
 
+// same product from the full symmetric LDS image S (row stride KP + 1): conflict-free row reads
+template <int KB>
+__device__ __forceinline__ void lds_matvec(const float* S, const int (&p)[KCfg<KB>::NR],
+                                           const float (&v)[KCfg<KB>::NR], float (&y)[KCfg<KB>::NR]) {
+    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) y[rr] = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < KP; ++j) {
+        const float vj = readlane_f(v[j >> 6], j & 63);
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) y[rr] = fmaf(S[j * (KP + 1) + p[rr]], vj, y[rr]);
+    }
+}
+
 template <int KB>
 __global__ __launch_bounds__(64)
 void k_w_item_vectors(int k, int64_t i0, int64_t i1, const float* __restrict__ gram,
@@ -55,6 +70,33 @@ void k_w_item_vectors(int k, int64_t i0, int64_t i1, const float* __restrict__ g
     if (i >= i1) return;
     const int lane = threadIdx.x;
     const float* G = gram + i * KP * KP;
+    // Up to KP = 112 the item's Gram is staged once as a full symmetric LDS image (coalesced row loads of
+    // the lower blocks, mirrored on the way in; diagonal blocks from their lower triangle, as gsym does);
+    // the nfeat + 1 products then read LDS rows instead of half-transposed global memory.
+    constexpr bool STAGE = KP * (KP + 1) * 4 <= 64 * 1024;
+    __shared__ float S[STAGE ? KP * (KP + 1) : 1];
+    if constexpr (STAGE) {
+        float gv[NR][16];
+        for (int r0 = 0; r0 < KP; r0 += 16) {
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int r = r0 + u, c = lane + 64 * rr;
+                    const bool ok = c < 16 * (r / 16 + 1) && !(c / 16 == r / 16 && c > r);
+                    gv[rr][u] = ok ? G[r * KP + c] : 0.f;
+                }
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int r = r0 + u, c = lane + 64 * rr;
+                    const bool ok = c < 16 * (r / 16 + 1) && !(c / 16 == r / 16 && c > r);
+                    if (ok) { S[r * (KP + 1) + c] = gv[rr][u]; S[c * (KP + 1) + r] = gv[rr][u]; }
+                }
+        }
+        wave_lds_sync();
+    }
     int p[NR], col[NR];
     float z[NR], gz[NR];
 #pragma unroll
@@ -65,7 +107,7 @@ void k_w_item_vectors(int k, int64_t i0, int64_t i1, const float* __restrict__ g
         for (int a = 0; a < D; ++a) s = fmaf(X[i * D + a], W[(int64_t)a * KP + col[rr]], s);    // z = V + sum_f xw_f
         z[rr] = s;
     }
-    gsym_matvec<KB>(G, p, z, gz);
+    if constexpr (STAGE) lds_matvec<KB>(S, p, z, gz); else gsym_matvec<KB>(G, p, z, gz);
     const float db = b_new[i] - b_old[i];
     float g[NR];
 #pragma unroll
@@ -78,7 +120,7 @@ void k_w_item_vectors(int k, int64_t i0, int64_t i1, const float* __restrict__ g
             for (int a = feat_off[f]; a < feat_off[f + 1]; ++a) s = fmaf(X[i * D + a], W[(int64_t)a * KP + col[rr]], s);
             xw[rr] = s;
         }
-        gsym_matvec<KB>(G, p, xw, gx);
+        if constexpr (STAGE) lds_matvec<KB>(S, p, xw, gx); else gsym_matvec<KB>(G, p, xw, gx);
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr)
             if (lane + 64 * rr < KP) H[((int64_t)f * nrows_h + i) * KP + p[rr]] = g[rr] + gx[rr];
@@ -191,34 +233,39 @@ template <int KB>
 __global__ __launch_bounds__(256)
 void k_w_reduce(int k, int nchunks, int d, const double* __restrict__ partA, const double* __restrict__ partB,
                 double* __restrict__ A, double* __restrict__ B) {
+    // grid (npairs, NACC + 1): y < NACC sums one lower block of the pair, y == NACC the b row (a == a' only)
     constexpr int KP = KCfg<KB>::KP, NACC = KCfg<KB>::NACC;
     int pair = blockIdx.x, a = 0;
     while (pair >= d - a) { pair -= d - a; ++a; }
     const int a2 = a + pair;
     const int64_t N = (int64_t)d * k;
     const int t = threadIdx.x, rr = t >> 4, cc = t & 15;
-    for (int q = 0; q < NACC; ++q) {
+    const int q = blockIdx.y;
+    if (q < NACC) {
+        const double* src = partA + (int64_t)blockIdx.x * nchunks * (NACC * 256) + q * 256 + t;
         double s = 0.0;
-        for (int c = 0; c < nchunks; ++c) s += partA[((int64_t)blockIdx.x * nchunks + c) * (NACC * 256) + q * 256 + t];
+#pragma unroll 8
+        for (int c = 0; c < nchunks; ++c) s += src[(int64_t)c * (NACC * 256)];
         int I, J;
         lower_block(q, I, J);
-        if (I == J && rr < cc) continue;           // the canonical twin (cc, rr) of this thread's element writes it
+        if (I == J && rr < cc) return;             // the canonical twin (cc, rr) of this thread's element writes it
         const int r = perm_to_col<KB>(16 * I + rr), c2 = perm_to_col<KB>(16 * J + cc);
-        if (r >= k || c2 >= k) continue;
+        if (r >= k || c2 >= k) return;
         const int64_t ra = (int64_t)a * k, rb = (int64_t)a2 * k;
         A[(ra + r) * N + rb + c2] = s;
         A[(ra + c2) * N + rb + r] = s;
         A[(rb + c2) * N + ra + r] = s;
         A[(rb + r) * N + ra + c2] = s;
-    }
-    if (a == a2)
+    } else if (a == a2) {
         for (int tt = t; tt < KP; tt += 256) {
             const int col = perm_to_col<KB>(tt);
             if (col >= k) continue;
             double s = 0.0;
+#pragma unroll 8
             for (int c = 0; c < nchunks; ++c) s += partB[((int64_t)a * nchunks + c) * KP + tt];
             B[(int64_t)a * k + col] = s;
         }
+    }
 }
 
 template <int KB>
@@ -235,7 +282,7 @@ int launch_w(const als_w_params* p, hipStream_t st) {
         hipLaunchKernelGGL(k_w_accumulate<KB>, dim3(npairs, p->nchunks), dim3(256), 0, st, p->item_begin,
                            p->item_end, p->nchunks, p->gram, p->D, p->feat_col0, d, p->X,
                            p->H + (int64_t)p->feat_index * p->nrows_h * KP, p->partA, p->partB);
-        hipLaunchKernelGGL(k_w_reduce<KB>, dim3(npairs), dim3(256), 0, st, p->k, p->nchunks, d, p->partA, p->partB,
+        hipLaunchKernelGGL(k_w_reduce<KB>, dim3(npairs, KCfg<KB>::NACC + 1), dim3(256), 0, st, p->k, p->nchunks, d, p->partA, p->partB,
                            p->A_out, p->B_out);
     }
     return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
