@@ -391,9 +391,8 @@ class _Engine:
                                 and not (self.multi and self.gs_mode == "exact"))
             if self.gs_dataflow:
                 self.S_idx_wait = torch.from_numpy(layout.wait_edges(ptr, idx, sched.level)).to(device)
-                self.gs_done = torch.zeros(n_pad, dtype=torch.int32, device=device)
+                self.gs_publish = torch.empty(n_pad, self.ld, dtype=f32, device=device)       # same shape as V
                 self.gs_err = torch.zeros(1, dtype=torch.int32, device=device)
-                self.gs_sweeps = 0
             self.factor = torch.zeros(n_pad * self.ld * self.ld, dtype=f32, device=device)
             self.sumr = torch.zeros(n_pad, dtype=f32, device=device)
         need_byproducts = self.use_graph or bool(self.feat_names)
@@ -547,9 +546,8 @@ class _Engine:
         if self.fused_stats:
             kw.update(sumr2=self.sumr2, lambda_eff=self.lam_eff, stat_out=self.stat_rows)
         if self.gs_dataflow:
-            self.gs_sweeps += 1
-            self.be.gs_dataflow(items=self.sched_items, S_idx_wait=self.S_idx_wait, done=self.gs_done,
-                                sweep_id=self.gs_sweeps, err=self.gs_err, **kw)
+            self.be.gs_dataflow(items=self.sched_items, S_idx_wait=self.S_idx_wait, publish=self.gs_publish,
+                                err=self.gs_err, **kw)
             return
         if not exact_multi and hasattr(self.be, "gs_levels"):
             # no collective between levels: the whole sweep is one C call (one launch per level)

@@ -165,6 +165,9 @@ void k_gs_level(const als_gs_sweep_params P) {
 // so they never need resetting.  Every spin is bounded: on timeout the wave raises `err` and
 // carries on with whatever it read (wrong numbers, no hang) - the host turns it into an error.
 // ---------------------------------------------------------------------------
+// "not yet published" marker of the dataflow sweep: a quiet NaN with a payload no arithmetic produces
+constexpr unsigned GS_SENTINEL = 0x7fc0dea1u;
+
 __device__ __forceinline__ float ld_agent(const float* p) {
     return __int_as_float(__hip_atomic_load(reinterpret_cast<const int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
@@ -174,7 +177,7 @@ __device__ __forceinline__ void st_agent(float* p, float v) {
 
 template <int KB>
 __global__ __launch_bounds__(256)
-void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, int32_t* done, int sweep_id,
+void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, float* pub,
                    int32_t* err, int64_t nitems, int nwaves) {
     using C = KCfg<KB>;
     constexpr int KP = C::KP, NR = C::NR;
@@ -211,18 +214,17 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
             cs_i[rr] = P.colsum[i64 * KP + ic[rr]];
             g[rr] = 0.f;
         }
+        // Pass 1 over the WHOLE neighbour list first: every neighbour that is NOT a dependency (j > i, or
+        // not swept) is gathered right away, so that none of these loads is issued behind a dependency
+        // wait.  Pass 2: the dependencies, always in ascending position order and GB per batch, each batch
+        // as soon as all its words are there.  The order of the floating-point sum never depends on timing:
+        // the sweep is bitwise reproducible.
+        constexpr int GB = (NR == 1) ? 16 : 8;
         for (int64_t t0 = s0; t0 < s1; t0 += 64) {
             const int nn = (int)min((int64_t)64, s1 - t0);
             const int raw = (lane < nn) ? Sw[t0 + lane] : item;
             const int sj_l = raw & 0x7fffffff;
-            const float sv_l = (lane < nn) ? P.S_val[t0 + lane] : 0.f;
-            // Pass 1: every neighbour that is NOT a dependency (j > i, or not swept) is gathered right
-            // away.  Pass 2: the dependencies, always in ascending position order and 16 per batch, each
-            // batch as soon as all its flags are up.  The order of the floating-point sum therefore never
-            // depends on timing: the sweep is bitwise reproducible.
-            const bool need = raw < 0;
-            const float sv_now = need ? 0.f : sv_l;
-            constexpr int GB = (NR == 1) ? 16 : 8;
+            const float sv_now = (lane < nn && raw >= 0) ? P.S_val[t0 + lane] : 0.f;
             for (int e0 = 0; e0 < nn; e0 += GB) {     // (dependency lanes ride along with weight 0)
                 float vv[GB][NR], sv[GB];
 #pragma unroll
@@ -237,14 +239,16 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
 #pragma unroll
                     for (int rr = 0; rr < NR; ++rr) g[rr] = fmaf(sv[e], vv[e][rr], g[rr]);
             }
-            // Dependencies: batches of GB in ascending position order.  A batch is gathered into ITS OWN
-            // partial sum as soon as all its flags are up (ready batches first, late ones after), and the
-            // partials are added in batch order at the end - processing order follows readiness, the order
-            // of the floating-point sum does not.
+        }
+        for (int64_t t0 = s0; t0 < s1; t0 += 64) {
+            const int nn = (int)min((int64_t)64, s1 - t0);
+            const int raw = (lane < nn) ? Sw[t0 + lane] : item;
+            const int sj_l = raw & 0x7fffffff;
+            const float sv_l = (lane < nn) ? P.S_val[t0 + lane] : 0.f;
+            const bool need = raw < 0;
             constexpr int NB = 64 / GB;
             unsigned long long dep = __ballot(need);
             if (dep) {
-                bool ok = !need || (__hip_atomic_load(done + sj_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sweep_id);
                 unsigned long long bm[NB];
                 float gp[NB][NR];
 #pragma unroll
@@ -263,14 +267,42 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
 #pragma unroll
                     for (int bb = 0; bb < NB; ++bb) {
                         if (bm[bb] == 0) continue;
-                        const bool mine = (bm[bb] >> lane) & 1;
-                        if (!bail && !__all(ok || !mine)) {
+                        // The rows of this batch come from the publication buffer, whose every word is the
+                        // sentinel until its producer has stored it: data and "ready" travel in the same
+                        // 4-byte word, one round trip, no flag, no ordering between words needed.
+                        unsigned long long m = bm[bb];
+                        float w[GB], v[GB][NR];
+                        int64_t off[GB];
+#pragma unroll
+                        for (int u = 0; u < GB; ++u) {
+                            const int src = m ? (int)__builtin_ctzll(m) : 0;
+                            w[u] = m ? __shfl(sv_l, src, 64) : 0.f;
+                            off[u] = m ? (int64_t)__shfl(sj_l, src, 64) * P.ld : -1;
+                            if (m) m &= m - 1;
+                        }
+                        bool rdy = true;
+#pragma unroll
+                        for (int u = 0; u < GB; ++u)
+#pragma unroll
+                            for (int rr = 0; rr < NR; ++rr) {
+                                v[u][rr] = (off[u] >= 0) ? ld_agent(pub + off[u] + col[rr]) : 0.f;
+                                rdy = rdy && (__float_as_uint(v[u][rr]) != GS_SENTINEL);
+                            }
+                        if (!bail && !__all(rdy)) {
                             if (round == 0) continue;                 // not ready yet: after the ready ones
                             const unsigned long long tstart = __builtin_amdgcn_s_memtime();
                             bail = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-                            while (!bail && !__all(ok || !mine)) {    // a timeout anywhere is sticky
+                            while (!bail && !__all(rdy)) {            // a timeout anywhere is sticky
                                 __builtin_amdgcn_s_sleep(1);
-                                if (!ok) ok = __hip_atomic_load(done + sj_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sweep_id;
+                                rdy = true;
+#pragma unroll
+                                for (int u = 0; u < GB; ++u)
+#pragma unroll
+                                    for (int rr = 0; rr < NR; ++rr) {
+                                        if (off[u] >= 0 && __float_as_uint(v[u][rr]) == GS_SENTINEL)
+                                            v[u][rr] = ld_agent(pub + off[u] + col[rr]);
+                                        rdy = rdy && (__float_as_uint(v[u][rr]) != GS_SENTINEL);
+                                    }
                                 if (__builtin_amdgcn_s_memtime() - tstart > SPIN_LIMIT ||
                                     __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                                     if (lane == 0) atomicExch(err, 1);
@@ -278,18 +310,7 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
                                 }
                             }
                         }
-                        unsigned long long m = bm[bb];
                         bm[bb] = 0;
-                        float w[GB], v[GB][NR];
-#pragma unroll
-                        for (int u = 0; u < GB; ++u) {
-                            const int src = m ? (int)__builtin_ctzll(m) : 0;
-                            w[u] = m ? __shfl(sv_l, src, 64) : 0.f;
-                            const int sj = __shfl(sj_l, src, 64);
-                            if (m) m &= m - 1;
-#pragma unroll
-                            for (int rr = 0; rr < NR; ++rr) v[u][rr] = ld_agent(P.V + (int64_t)sj * P.ld + col[rr]);
-                        }
 #pragma unroll
                         for (int u = 0; u < GB; ++u)
 #pragma unroll
@@ -310,13 +331,15 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
             for (int rr = 0; rr < NR; ++rr) x[rr] = rhs_i[rr] + P.alpha * g[rr];
             solve_stream<KB>(M, x, lane, y);
         }
-        // publish first: every store of the row has left the wave before the flag does; the bias
-        // and the statistics below are nobody's dependency
+        // publish first (write-through stores into the publication buffer; each word is its own "ready"
+        // flag); V itself is read again only by later launches.  The bias and the statistics below are
+        // nobody's dependency.
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr)
-            if (lane + 64 * rr < KP) st_agent(P.V + i64 * P.ld + col[rr], x[rr]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(done + item, sweep_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane + 64 * rr < KP) {
+                st_agent(pub + i64 * P.ld + col[rr], x[rr]);
+                P.V[i64 * P.ld + col[rr]] = x[rr];
+            }
         float dot = 0.f, xr = 0.f, yy = 0.f, xx = 0.f;
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr)
@@ -346,14 +369,14 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
 }
 
 template <int KB>
-int launch_gs_dataflow(const als_gs_sweep_params* p, const int32_t* Sw, int32_t* done, int sweep_id,
+int launch_gs_dataflow(const als_gs_sweep_params* p, const int32_t* Sw, float* pub,
                        int32_t* err, int64_t nitems, hipStream_t st) {
     // two 4-wave workgroups per CU (<= 222 VGPRs, no LDS: at least 2 waves per SIMD fit): 2048 waves
     // are always co-resident on the 256-CU part
     int nwg = 512;
     if ((int64_t)nwg * 4 > nitems) nwg = (int)((nitems + 3) / 4);
     if (nwg < 1) return 0;
-    hipLaunchKernelGGL(k_gs_dataflow<KB>, dim3(nwg), dim3(256), 0, st, *p, Sw, done, sweep_id, err, nitems, nwg * 4);
+    hipLaunchKernelGGL(k_gs_dataflow<KB>, dim3(nwg), dim3(256), 0, st, *p, Sw, pub, err, nitems, nwg * 4);
     return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
 }
 
@@ -368,9 +391,9 @@ int launch_gs(const als_gs_sweep_params* p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t* S_idx_wait, int32_t* done,
-                                     int32_t sweep_id, int32_t* err, void* stream) {
-    if (!p || !S_idx_wait || !done || !err || sweep_id <= 0) return ALS_E_BADARG;
+extern "C" int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t* S_idx_wait, float* publish,
+                                     int64_t nrows, int32_t* err, void* stream) {
+    if (!p || !S_idx_wait || !publish || !err || nrows < 0) return ALS_E_BADARG;
     const int ld = als_padded_k(p->k);
     if (ld < 0) return ALS_E_BADK;
     if (p->ld != ld || p->nitems < 0 || !p->S_ptr || !p->S_val || !p->factor || !p->rhs || !p->colsum ||
@@ -378,17 +401,20 @@ extern "C" int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t
         return ALS_E_BADARG;
     if (p->stat_out && (!p->sumr2 || !p->lambda_eff)) return ALS_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    if (p->nitems > 0 && nrows > 0 &&
+        hipMemsetD32Async((hipDeviceptr_t)publish, (int)GS_SENTINEL, (size_t)nrows * ld, st) != hipSuccess)
+        return ALS_E_LAUNCH;
     switch (ld / 16) {
-        case 1: return launch_gs_dataflow<1>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
-        case 2: return launch_gs_dataflow<2>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
-        case 3: return launch_gs_dataflow<3>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
-        case 4: return launch_gs_dataflow<4>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
-        case 5: return launch_gs_dataflow<5>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
-        case 6: return launch_gs_dataflow<6>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
-        case 7: return launch_gs_dataflow<7>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
-        case 8: return launch_gs_dataflow<8>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
-        case 9: return launch_gs_dataflow<9>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
-        case 10: return launch_gs_dataflow<10>(p, S_idx_wait, done, sweep_id, err, p->nitems, st);
+        case 1: return launch_gs_dataflow<1>(p, S_idx_wait, publish, err, p->nitems, st);
+        case 2: return launch_gs_dataflow<2>(p, S_idx_wait, publish, err, p->nitems, st);
+        case 3: return launch_gs_dataflow<3>(p, S_idx_wait, publish, err, p->nitems, st);
+        case 4: return launch_gs_dataflow<4>(p, S_idx_wait, publish, err, p->nitems, st);
+        case 5: return launch_gs_dataflow<5>(p, S_idx_wait, publish, err, p->nitems, st);
+        case 6: return launch_gs_dataflow<6>(p, S_idx_wait, publish, err, p->nitems, st);
+        case 7: return launch_gs_dataflow<7>(p, S_idx_wait, publish, err, p->nitems, st);
+        case 8: return launch_gs_dataflow<8>(p, S_idx_wait, publish, err, p->nitems, st);
+        case 9: return launch_gs_dataflow<9>(p, S_idx_wait, publish, err, p->nitems, st);
+        case 10: return launch_gs_dataflow<10>(p, S_idx_wait, publish, err, p->nitems, st);
     }
     return ALS_E_BADK;
 }

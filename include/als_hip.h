@@ -181,11 +181,12 @@ int als_gs_sweep(const als_gs_sweep_params* p, void* stream);
 
 /* Whole sweep as ONE persistent launch without level barriers.  p->items lists ALL swept
  * items in (level, id) order (p->nitems of them).  S_idx_wait is p->S_idx with the sign bit set on
- * every edge (i -> j) that item i must wait for (j < i and j swept in this call).  done: int32[n]
- * flags, zero before the first sweep; sweep_id > 0 must increase from call to call.  err: int32[1],
- * set to 1 if a dependency wait timed out (results are then invalid). */
-int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t* S_idx_wait, int32_t* done,
-                          int32_t sweep_id, int32_t* err, void* stream);
+ * every edge (i -> j) that item i must wait for (j < i and j swept in this call).  publish: scratch
+ * [nrows][ld] floats (nrows = rows of p->V); the call resets it and the kernel hands solved rows from
+ * producer to consumer through it (each word doubles as its own "ready" flag).  err: int32[1], set to
+ * 1 if a dependency wait timed out (results are then invalid). */
+int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t* S_idx_wait, float* publish,
+                          int64_t nrows, int32_t* err, void* stream);
 
 /* Whole sweep in one call: level l covers p->items[level_offsets[l] .. level_offsets[l+1]) (host
  * array of nlevels+1 offsets into the device array p->items; p->nitems is ignored).  One launch per
