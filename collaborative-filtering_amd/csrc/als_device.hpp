@@ -208,45 +208,107 @@ __device__ __forceinline__ void solve_stream(const float* __restrict__ M, float 
 
 // any KP, L in LDS: Al[j*LD + i] = L[i][j] (i > j), dinv[j] = 1/L[j][j].
 // vec[] (LDS, perm space) holds b on entry and x on exit.
+//
+// Both substitutions run in blocks of 16 steps whose LDS operands are fetched one block ahead (the reads
+// do not depend on the running right-hand side, only the FMA chain does).  The running vector is kept
+// unscaled: lane j's entry is final once step j has passed, y = rb * dinv is applied at the hand-over and
+// at the end, which removes the per-step "lane == j" select.  JB / IB (the 64-lane group of the pivot)
+// is a template parameter, so groups that a step cannot touch cost no instruction and only the pivot's
+// own group needs the i > j (j < ii) mask.
+template <int KB, int LD, int JB>
+__device__ __forceinline__ void lds_fwd_group(const float* __restrict__ Al, const float (&di)[KCfg<KB>::NR],
+                                              float (&rb)[KCfg<KB>::NR], const int (&ci)[KCfg<KB>::NR],
+                                              float (&cur)[16][KCfg<KB>::NR], int lane) {
+    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR, SB = 16;
+    constexpr int JEND = (64 * JB + 64 < KP) ? 64 * JB + 64 : KP;
+    float nxt[SB][NR];
+    for (int j0 = 64 * JB; j0 < JEND; j0 += SB) {
+        if (j0 + SB < KP) {
+#pragma unroll
+            for (int u = 0; u < SB; ++u)
+#pragma unroll
+                for (int rr = JB; rr < NR; ++rr) nxt[u][rr] = Al[(j0 + SB + u) * LD + ci[rr]];
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int j = j0 + u;
+            const float yj = readlane_f(rb[JB] * di[JB], j & 63);
+            rb[JB] = fmaf((lane + 64 * JB > j) ? -cur[u][JB] : 0.f, yj, rb[JB]);
+#pragma unroll
+            for (int rr = JB + 1; rr < NR; ++rr) rb[rr] = fmaf(-cur[u][rr], yj, rb[rr]);
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u)
+#pragma unroll
+            for (int rr = JB; rr < NR; ++rr) cur[u][rr] = nxt[u][rr];
+    }
+    if constexpr (JB + 1 < NR) lds_fwd_group<KB, LD, JB + 1>(Al, di, rb, ci, cur, lane);
+}
+
+template <int KB, int LD, int IB>
+__device__ __forceinline__ void lds_bwd_group(const float* __restrict__ Al, const float (&di)[KCfg<KB>::NR],
+                                              float (&rb)[KCfg<KB>::NR], const int (&ci)[KCfg<KB>::NR],
+                                              float (&cur)[16][KCfg<KB>::NR], int lane) {
+    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR, SB = 16;
+    constexpr int ITOP = ((64 * IB + 64 < KP) ? 64 * IB + 64 : KP) - 1;
+    float nxt[SB][NR];
+    for (int i0 = ITOP; i0 >= 64 * IB; i0 -= SB) {
+        if (i0 - SB >= 0) {
+#pragma unroll
+            for (int u = 0; u < SB; ++u)
+#pragma unroll
+                for (int rr = 0; rr <= IB; ++rr) nxt[u][rr] = Al[ci[rr] * LD + (i0 - SB - u)];
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int ii = i0 - u;
+            const float xi = readlane_f(rb[IB] * di[IB], ii & 63);
+            rb[IB] = fmaf((lane + 64 * IB < ii) ? -cur[u][IB] : 0.f, xi, rb[IB]);
+#pragma unroll
+            for (int rr = 0; rr < IB; ++rr) rb[rr] = fmaf(-cur[u][rr], xi, rb[rr]);
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u)
+#pragma unroll
+            for (int rr = 0; rr <= IB; ++rr) cur[u][rr] = nxt[u][rr];
+    }
+    if constexpr (IB > 0) lds_bwd_group<KB, LD, IB - 1>(Al, di, rb, ci, cur, lane);
+}
+
 template <int KB, int LD>
 __device__ __forceinline__ void solve_lds(const float* __restrict__ Al, const float* __restrict__ dinv,
-                                          float* __restrict__ vec, int lane) {
-    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR;
+                                          float* __restrict__ vec, int lane, float* y_out = nullptr) {
+    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR, SB = 16;
+    static_assert(KP % SB == 0, "KP is a multiple of 16");
     float rb[NR], di[NR];
+    int ci[NR];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
         const int i = lane + 64 * rr;
+        ci[rr] = min(i, KP - 1);
         rb[rr] = (i < KP) ? vec[i] : 0.f;
         di[rr] = (i < KP) ? dinv[i] : 0.f;
     }
-    for (int j = 0; j < KP; ++j) {            // L y = b
-        float yj = 0.f;
+    float cur[SB][NR];
 #pragma unroll
-        for (int rr = 0; rr < NR; ++rr) {
-            const float cand = readlane_f(rb[rr] * di[rr], j & 63);
-            if ((j >> 6) == rr) yj = cand;
-        }
+    for (int u = 0; u < SB; ++u)
 #pragma unroll
-        for (int rr = 0; rr < NR; ++rr) {
-            const int i = lane + 64 * rr;
-            if (i == j) rb[rr] = yj;
-            else if (i > j && i < KP) rb[rr] = fmaf(-Al[j * LD + i], yj, rb[rr]);
-        }
+        for (int rr = 0; rr < NR; ++rr) cur[u][rr] = Al[u * LD + ci[rr]];
+    lds_fwd_group<KB, LD, 0>(Al, di, rb, ci, cur, lane);                 // L y = b
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) rb[rr] *= di[rr];                   // y
+    if (y_out) {
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) y_out[rr] = rb[rr];
     }
-    for (int ii = KP - 1; ii >= 0; --ii) {    // L^T x = y
-        float xi = 0.f;
+    // L^T x = y: step ii needs L[ii][j] = Al[j * LD + ii] for the lanes j < ii
 #pragma unroll
-        for (int rr = 0; rr < NR; ++rr) {
-            const float cand = readlane_f(rb[rr] * di[rr], ii & 63);
-            if ((ii >> 6) == rr) xi = cand;
-        }
+    for (int u = 0; u < SB; ++u)
 #pragma unroll
-        for (int rr = 0; rr < NR; ++rr) {
-            const int j = lane + 64 * rr;
-            if (j == ii) rb[rr] = xi;
-            else if (j < ii) rb[rr] = fmaf(-Al[j * LD + ii], xi, rb[rr]);
-        }
-    }
+        for (int rr = 0; rr < NR; ++rr) cur[u][rr] = Al[ci[rr] * LD + (KP - 1 - u)];
+    lds_bwd_group<KB, LD, NR - 1>(Al, di, rb, ci, cur, lane);
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) rb[rr] *= di[rr];                   // x
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
         const int i = lane + 64 * rr;

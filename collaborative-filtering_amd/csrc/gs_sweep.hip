@@ -150,7 +150,7 @@ void k_gs_level(const als_gs_sweep_params P) {
 }
 
 // ---------------------------------------------------------------------------
-// K2': the whole sweep as ONE persistent, synchronisation-free launch (k <= 64).
+// K2': the whole sweep as ONE persistent, synchronisation-free launch.
 //
 // Items are listed in (level, id) order and dealt round-robin to `nwaves` co-resident waves
 // (one workgroup per CU); each wave walks its items in that order.  An item waits only for the
@@ -176,14 +176,27 @@ __device__ __forceinline__ void st_agent(float* p, float v) {
 }
 
 template <int KB>
-__global__ __launch_bounds__(256)
+struct DfCfg {   // k <= 64: factor column in registers, 4 waves per workgroup; k > 64: one wave per
+                 // workgroup with the item's factor staged as a [KP][KP+1] LDS image before the waits
+    static constexpr int WPW = (KB <= 4) ? 4 : 1;
+    static constexpr int LD = KCfg<KB>::KP + 1;
+    static constexpr int IMG = (KB <= 4) ? 1 : KCfg<KB>::KP * LD + 3 * KCfg<KB>::KP;
+};
+
+template <int KB>
+__global__ __launch_bounds__(64 * DfCfg<KB>::WPW)
 void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, float* pub,
                    int32_t* err, int64_t nitems, int nwaves) {
     using C = KCfg<KB>;
     constexpr int KP = C::KP, NR = C::NR;
+    constexpr int LD = DfCfg<KB>::LD;
     constexpr unsigned long long SPIN_LIMIT = 1ull << 28;      // ~0.12 s of shader clock
+    __shared__ float lds_img[DfCfg<KB>::IMG];
+    float* Al = lds_img;
+    float* vec = lds_img + ((KB <= 4) ? 0 : KP * LD);
+    float* dinv = vec + ((KB <= 4) ? 0 : 2 * KP);
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int gw = blockIdx.x * DfCfg<KB>::WPW + (threadIdx.x >> 6);
     int ic[NR], col[NR];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
@@ -206,6 +219,24 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
 #pragma unroll
             for (int p = 0; p < KP; ++p) a[p] = M[p * KP + ic[0]];
             di0 = M[ic[0] * KP + ic[0]];
+        } else {
+            // k > 64: the whole factor (M = L + L^T, 1/diag on the diagonal: row p is also column p) goes
+            // into this wave's LDS image now, underneath the waits, 8 row loads in flight
+            for (int p0 = 0; p0 < KP; p0 += 8) {
+                float t[8][NR];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr) t[u][rr] = M[(p0 + u) * KP + ic[rr]];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr)
+                        if (lane + 64 * rr < KP) {
+                            Al[(p0 + u) * LD + ic[rr]] = t[u][rr];
+                            if (ic[rr] == p0 + u) dinv[ic[rr]] = t[u][rr];
+                        }
+            }
         }
         float rhs_i[NR], cs_i[NR], g[NR];
 #pragma unroll
@@ -240,11 +271,17 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
                     for (int rr = 0; rr < NR; ++rr) g[rr] = fmaf(sv[e], vv[e][rr], g[rr]);
             }
         }
+        // (the next chunk's indices and weights are fetched before this chunk's dependencies are waited for)
+        int raw_n = (s0 + lane < s1) ? Sw[s0 + lane] : item;
+        float sv_n = (s0 + lane < s1) ? P.S_val[s0 + lane] : 0.f;
         for (int64_t t0 = s0; t0 < s1; t0 += 64) {
-            const int nn = (int)min((int64_t)64, s1 - t0);
-            const int raw = (lane < nn) ? Sw[t0 + lane] : item;
+            const int raw = raw_n;
+            const float sv_l = sv_n;
+            if (t0 + 64 < s1) {
+                raw_n = (t0 + 64 + lane < s1) ? Sw[t0 + 64 + lane] : item;
+                sv_n = (t0 + 64 + lane < s1) ? P.S_val[t0 + 64 + lane] : 0.f;
+            }
             const int sj_l = raw & 0x7fffffff;
-            const float sv_l = (lane < nn) ? P.S_val[t0 + lane] : 0.f;
             const bool need = raw < 0;
             constexpr int NB = 64 / GB;
             unsigned long long dep = __ballot(need);
@@ -328,8 +365,13 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
             x[0] = solve_regs<KP>(a, di0, rhs_i[0] + P.alpha * g[0], lane, &y[0]);
         } else {
 #pragma unroll
-            for (int rr = 0; rr < NR; ++rr) x[rr] = rhs_i[rr] + P.alpha * g[rr];
-            solve_stream<KB>(M, x, lane, y);
+            for (int rr = 0; rr < NR; ++rr)
+                if (lane + 64 * rr < KP) vec[ic[rr]] = rhs_i[rr] + P.alpha * g[rr];
+            wave_lds_sync();
+            solve_lds<KB, LD>(Al, dinv, vec, lane, y);
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) x[rr] = vec[ic[rr]];
+            wave_lds_sync();                 // the image is refilled for the next item
         }
         // publish first (write-through stores into the publication buffer; each word is its own "ready"
         // flag); V itself is read again only by later launches.  The bias and the statistics below are
@@ -371,12 +413,19 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
 template <int KB>
 int launch_gs_dataflow(const als_gs_sweep_params* p, const int32_t* Sw, float* pub,
                        int32_t* err, int64_t nitems, hipStream_t st) {
-    // two 4-wave workgroups per CU (<= 222 VGPRs, no LDS: at least 2 waves per SIMD fit): 2048 waves
-    // are always co-resident on the 256-CU part
-    int nwg = 512;
-    if ((int64_t)nwg * 4 > nitems) nwg = (int)((nitems + 3) / 4);
+    // Every wave of the launch must be co-resident on the 256-CU part.  k <= 64: two 4-wave workgroups
+    // per CU (<= 256 VGPRs, no LDS: 2 waves per SIMD fit) = 2048 waves.  k > 64: one-wave workgroups,
+    // as many per CU as their LDS images fit into 160 KB (2 at k = 128, 1 at k = 160), at most 8.
+    constexpr int WPW = DfCfg<KB>::WPW;
+    int per_cu = 2;
+    if (KB > 4) {
+        per_cu = (160 * 1024) / (int)(DfCfg<KB>::IMG * sizeof(float));
+        if (per_cu > 8) per_cu = 8;
+    }
+    int nwg = 256 * per_cu;
+    if ((int64_t)nwg * WPW > nitems) nwg = (int)((nitems + WPW - 1) / WPW);
     if (nwg < 1) return 0;
-    hipLaunchKernelGGL(k_gs_dataflow<KB>, dim3(nwg), dim3(256), 0, st, *p, Sw, pub, err, nitems, nwg * 4);
+    hipLaunchKernelGGL(k_gs_dataflow<KB>, dim3(nwg), dim3(64 * WPW), 0, st, *p, Sw, pub, err, nitems, nwg * WPW);
     return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
 }
 
