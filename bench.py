@@ -213,7 +213,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", default="cfg4", choices=sorted(SIZES))
-    ap.add_argument("--gs-mode", default=None, choices=[None, "exact", "block"])
+    ap.add_argument("--gs-mode", default=None, choices=[None, "exact", "block", "levels"],
+                    help="Laplacian sweep with several ranks: exact (default; shards in rank order), block, levels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="debug only; not a valid headline run")
     ap.add_argument("--gram", default="bf16x3", choices=["bf16x3", "f32"],

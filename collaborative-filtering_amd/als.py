@@ -376,19 +376,27 @@ class _Engine:
                 D = (csum[self.S_ptr[1:]] - csum[self.S_ptr[:-1]]).to(f32)
             self.diag_extra = torch.zeros(n_pad, dtype=f32, device=device)
             self.diag_extra[: self.n] = np.float32(model.alpha) * D
-            self.gs_mode = gs_mode or ("block" if self.multi else "exact")
-            if self.gs_mode not in ("exact", "block"):
+            # Sweep modes with several ranks (one rank: all the same thing):
+            #   "exact"  (default) the item shards sweep ONE AFTER THE OTHER in rank order, each followed by a
+            #            broadcast of its rows: shard r sees the new rows of shards < r and the old rows of
+            #            shards > r - the reference's Gauss-Seidel order, at the cost of a sweep that does not
+            #            scale with the number of ranks;
+            #   "block"  all shards sweep at once, rows of other shards are the previous iteration's
+            #            (Gauss-Seidel inside a shard, Jacobi across shards: approximate, scales);
+            #   "levels" global level schedule with an exchange after every level (exact; one collective per level).
+            self.gs_mode = gs_mode or "exact"
+            if self.gs_mode not in ("exact", "block", "levels"):
                 raise ValueError(f"unknown gs_mode '{self.gs_mode}'")
             active = counts > 0
-            if self.gs_mode == "block" or not self.multi:
-                sched = layout.build_level_schedule(ptr, idx, active, self.ib, self.ie)
-            else:
+            if self.multi and self.gs_mode == "levels":
                 sched = layout.build_level_schedule(ptr, idx, active, 0, self.n)
+            else:
+                sched = layout.build_level_schedule(ptr, idx, active, self.ib, self.ie)
             self.sched = sched
             self.sched_items = torch.from_numpy(sched.items).to(device)
             # persistent dataflow sweep (one launch, no level barriers) when the backend has it
             self.gs_dataflow = (hasattr(backend, "gs_dataflow")
-                                and not (self.multi and self.gs_mode == "exact"))
+                                and not (self.multi and self.gs_mode == "levels"))
             if self.gs_dataflow:
                 self.S_idx_wait = torch.from_numpy(layout.wait_edges(ptr, idx, sched.level)).to(device)
                 self.gs_publish = torch.empty(n_pad, self.ld, dtype=f32, device=device)       # same shape as V
@@ -436,6 +444,9 @@ class _Engine:
             return
         mine = t[self.rank * per:(self.rank + 1) * per].clone()
         dist.all_gather_into_tensor(t.view(-1), mine.view(-1), group=self.pg)
+
+    def _global_rank(self, r: int) -> int:
+        return r if self.pg is None else dist.get_global_rank(self.pg, r)
 
     def _allreduce(self, t: torch.Tensor):
         if self.multi:
@@ -530,6 +541,17 @@ class _Engine:
                                   sumr_out=self.sumr, sumr2_out=self.sumr2 if self.fused_stats else None,
                                   **common)
             # phase B (sequential in levels): Gauss-Seidel sweep with live V (:458)
+            if self.multi and self.gs_mode == "exact":
+                # shards in rank order; the broadcast hands shard r's new rows to everybody before shard
+                # r + 1 starts (stream-ordered on every rank)
+                with self._tick("gs_sweep"):
+                    for r in range(self.world):
+                        if r == self.rank:
+                            self._gs_sweep()
+                        dist.broadcast(self.V[r * self.i_per:(r + 1) * self.i_per], src=self._global_rank(r),
+                                       group=self.pg)
+                self._allgather_rows(self.b_i, self.i_per)
+                return
             with self._tick("gs_sweep"):
                 self._gs_sweep()
         self._allgather_rows(self.V, self.i_per)
@@ -538,7 +560,7 @@ class _Engine:
     def _gs_sweep(self):
         md = self.model
         off = self.sched.offsets
-        exact_multi = self.multi and self.gs_mode == "exact"
+        exact_multi = self.multi and self.gs_mode == "levels"
         kw = dict(k=self.k, ld=self.ld, S_ptr=self.S_ptr, S_idx=self.S_idx, S_val=self.S_val,
                   alpha=md.alpha, factor=self.factor, rhs=self.rhs_out, colsum=self.colsum_out,
                   sumr=self.sumr, indptr=self.csc.indptr, lam_b=md.lambda_bi, lam_b_row=None,

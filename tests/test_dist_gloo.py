@@ -81,17 +81,33 @@ def test_two_ranks_equal_one_rank(name):
     np.testing.assert_allclose(outs[0]["rmse"], g.d["hist_train_rmse"], atol=2e-6)
 
 
-def test_exact_gauss_seidel_across_ranks():
-    """gs_mode='exact': per-level exchange of fresh V rows reproduces the sequential sweep."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_exact_gauss_seidel_across_ranks(world):
+    """gs_mode='exact' (the default): the item shards sweep one after the other in rank order, each
+    followed by a broadcast of its rows - the reference's Gauss-Seidel order.  Every item sees the same
+    neighbour values as in the single-process sweep and sums them in the same order: bitwise equal."""
     g, ref = _single("g5_graph_a0.5")
-    outs = _run("g5_graph_a0.5", gs_mode="exact")
+    outs = _run("g5_graph_a0.5", world=world)
+    for r in range(1, world):
+        np.testing.assert_array_equal(outs[0]["V"], outs[r]["V"])
+        np.testing.assert_array_equal(outs[0]["b_i"], outs[r]["b_i"])
+    np.testing.assert_array_equal(outs[0]["V"], ref.V)
+    np.testing.assert_array_equal(outs[0]["U"], ref.U)
+    np.testing.assert_allclose(outs[0]["rmse"], ref.history["train_rmse"], rtol=1e-12)
+    np.testing.assert_allclose(outs[0]["rmse"], g.d["hist_train_rmse"], atol=2e-6)
+
+
+def test_level_exchange_gauss_seidel_across_ranks():
+    """gs_mode='levels': global level schedule, exchange of the fresh V rows after every level."""
+    g, ref = _single("g5_graph_a0.5")
+    outs = _run("g5_graph_a0.5", gs_mode="levels")
     np.testing.assert_array_equal(outs[0]["V"], outs[1]["V"])
     np.testing.assert_allclose(outs[0]["V"], ref.V, rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(outs[0]["rmse"], g.d["hist_train_rmse"], atol=2e-6)
 
 
 def test_block_gauss_seidel_is_close_and_consistent():
-    """gs_mode='block' (default for N>1): Gauss-Seidel inside an item shard, previous-iteration
+    """gs_mode='block' (opt-in): Gauss-Seidel inside an item shard, previous-iteration
     values across shards.  Not the reference's order - the deviation is bounded here and stated
     in DESIGN.md; both ranks must still agree bitwise."""
     g, ref = _single("g5_graph_a0.5")
@@ -134,7 +150,7 @@ def _forced_worker(rank, world, port, name, gs_mode, outdir):
     _worker(rank, world, port, name, gs_mode, outdir)
 
 
-@pytest.mark.parametrize("gs_mode", ["block", "exact"])
+@pytest.mark.parametrize("gs_mode", ["block", "exact", "levels"])
 def test_forced_collectives_on_one_rank(gs_mode):
     """ALS_FORCE_COLLECTIVES=1 takes the sharded code path (chunked U-step with async all-gathers,
     per-level exchange in exact mode) on a one-rank group - the rehearsal mode `bench.py` uses to
