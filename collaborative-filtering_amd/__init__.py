@@ -12,7 +12,8 @@ from .helpers import (ES_MIN_ITERS, ES_TOL, DEFAULT_RANDOM_STATE, cholesky_solve
                       normalize_params, rmse_on_indices)
 
 from . import cv                     # sparse CV / ablation harness
+from . import features               # feature normaliser
 
-__all__ = ["ALS", "cv", "ALSConfig", "BiasesConfig", "CoreConfig", "GraphConfig", "GraphSimConfig",
+__all__ = ["ALS", "cv", "features", "ALSConfig", "BiasesConfig", "CoreConfig", "GraphConfig", "GraphSimConfig",
            "cholesky_solve", "make_config", "normalize_params", "rmse_on_indices",
            "ES_TOL", "ES_MIN_ITERS", "DEFAULT_RANDOM_STATE"]

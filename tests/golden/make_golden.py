@@ -124,8 +124,34 @@ def folds_case():
     print("folds fixture:", [len(f) for f in folds])
 
 
+def feature_norm_case():
+    """Outputs of the reference's scripts/prepare_features.py on a seeded matrix with NaN / +-inf entries,
+    an all-zero row, a constant column and an all-missing column (every method, both impute modes)."""
+    from scripts.prepare_features import normalize_feature, normalize_features_dict
+    rng = np.random.default_rng(301)
+    X = rng.normal(size=(50, 6)) * 3.0 + 1.0
+    X[:, 2] = 7.0                       # constant column
+    X[:, 5] = np.nan                    # all-missing column
+    X[3, 1], X[5, 0], X[6, 4] = np.nan, np.inf, -np.inf
+    X[7, :5] = 0.0                      # zero row (row norms clamp to eps)
+    clean = rng.normal(size=(50, 4))
+    years = rng.integers(1950, 2020, size=50).astype(np.float64)
+    out = {"X": X, "clean": clean, "years": years}
+    for method in ("none", "row_l1", "row_l2", "col_zscore", "col_minmax"):
+        out[f"imputed_{method}"] = normalize_feature(X, method, impute="col_median")
+        out[f"clean_{method}"] = normalize_feature(clean, method)
+        out[f"clean64_{method}"] = normalize_feature(clean, method, dtype="float64")
+    d = normalize_features_dict({"genres": clean, "years": years}, method="none", impute="col_median",
+                                per_feature_overrides={"genres": {"method": "row_l2"},
+                                                       "years": {"method": "col_zscore"}})
+    out["dict_genres"], out["dict_years"] = d["genres"], d["years"]
+    np.savez_compressed(os.path.join(HERE, "feat_norm_50x6.npz"), **out)
+    print("feature-normaliser fixture:", sorted(out)[:4], "...")
+
+
 def main():
     folds_case()
+    feature_norm_case()
     sim10 = dict(source="feature", feature_name="genres", metric="cosine",
                  topk=10, eps=1e-8)
     # g1: plain U/V (+ the always-on mu / bias terms)
