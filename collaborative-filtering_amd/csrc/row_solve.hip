@@ -408,14 +408,19 @@ __device__ __forceinline__ void backward_solve(const float* __restrict__ Ls, con
     constexpr int KP = C::KP, NR = C::NR;
     const int c = lane & 15;
     float rs[NR];
-    int colbase[NR], rowmin[NR];
+    int colbase[NR][4];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
         const int i = min(lane + 64 * rr, KP - 1);
         const int Ji = i >> 4;
         rs[rr] = S.y[rr] * S.di[rr];
-        colbase[rr] = C::lcol_off_rt(Ji) - 16 * Ji * 16 + (c & 3);    // + row * 16 + group * 4
-        rowmin[rr] = 16 * Ji;                                         // first row of the lane's block column
+        // element (row, lane's column) of the lane's block column sits at base[g] + row * 16, g = (row >> 2) & 3
+        // selecting the swizzled 4-float group.  Rows above the block column (row < 16 Ji) are masked
+        // below; their addresses stay inside this wave's image (lcol_off(J) >= 256 J), so the read needs
+        // no clamp and every address is one of four per-lane bases plus a compile-time offset.
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            colbase[rr][g] = C::lcol_off_rt(Ji) - 16 * Ji * 16 + (c & 3) + (((c >> 2) ^ g) << 2);
     }
 #pragma unroll
     for (int pb = KB - 1; pb >= 0; --pb) {
@@ -426,9 +431,7 @@ __device__ __forceinline__ void backward_solve(const float* __restrict__ Ls, con
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int prow = 16 * pb + t;
-                const int grp = ((c >> 2) ^ ((t >> 2) & 3)) << 2;
-                const int rsafe = max(prow, rowmin[rr]);                  // stay inside the block column
-                const float v = Ls[colbase[rr] + rsafe * 16 + grp];
+                const float v = Ls[colbase[rr][(t >> 2) & 3] + prow * 16];
                 cf[rr][t] = (prow > i) ? v * S.di[rr] : 0.f;
             }
         }
