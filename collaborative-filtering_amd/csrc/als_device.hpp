@@ -25,6 +25,21 @@ __device__ __forceinline__ float bperm_f(float v, int src_lane) {
 __device__ __forceinline__ int bperm_i(int v, int src_lane) {
     return __builtin_amdgcn_ds_bpermute(src_lane << 2, v);
 }
+// (lane in MASK) ? a : b with a compile-time lane mask: the inverse ballot of a literal turns into one
+// v_cndmask on an SGPR-pair constant instead of v_cmp (lane, literal) + v_cndmask - the compiler cannot know
+// that a comparison of the lane id with a literal is a literal mask.  (No inline asm: the hazard recogniser
+// does not see into it, and a VALU write next to MFMAs needs its wait states.)
+template <unsigned long long MASK>
+__device__ __forceinline__ float select_lanes(float a, float b) {
+    return __builtin_amdgcn_inverse_ballot_w64(MASK) ? a : b;
+}
+// lanes with lane + 64 * RR < BOUND
+template <int BOUND, int RR>
+constexpr unsigned long long lanes_below() {
+    constexpr int n = BOUND - 64 * RR;
+    return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -21,6 +21,7 @@
 // panel loop (the right-hand side is one more value per lane), so only the
 // transposed solve is a separate pass.  VALU work is O(k^2 * 16), the O(k^3)
 // part is MFMA.  L lives in LDS as swizzled block columns: 10 KB at k = 64.
+#include <type_traits>
 #include "als_device.hpp"
 #include "als_hip.h"
 
@@ -295,7 +296,7 @@ __device__ __forceinline__ void panel_pivot(float (&p)[KCfg<KB>::NR][16], Chol<K
     float l[NR];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) { l[rr] = p[rr][T] * inv; p[rr][T] = l[rr]; }
-    if (lane == LP) S.di[RP] = inv;
+    S.di[RP] = select_lanes<1ull << LP>(inv, S.di[RP]);
     // multipliers L[16J+t2][16J+T] first (wave-uniform, in SGPRs), then the FMAs: keeps the
     // v_readlane -> SGPR -> VALU hazard slots filled with independent work
     float s[16 - T > 1 ? 15 - T : 1];
@@ -311,7 +312,7 @@ __device__ __forceinline__ void panel_pivot(float (&p)[KCfg<KB>::NR][16], Chol<K
     if constexpr (SOLVE) {
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) S.b[rr] = fmaf(-l[rr], yt, S.b[rr]);
-        if (lane == LP) S.y[RP] = yt;
+        S.y[RP] = select_lanes<1ull << LP>(yt, S.y[RP]);
     }
 }
 
@@ -399,6 +400,26 @@ __device__ __forceinline__ void chol_panels(RowAcc<KB>& A, Chol<KB>& S, float* _
     }
 }
 
+// coefficients of one 16-step block of the transposed solve: cf[rr][t] = L[16 pb + t][i] / L[i][i] for the
+// lanes i = lane + 64 rr below the pivot row, 0 elsewhere (compile-time lane masks)
+template <int KB, int RR, int T, int PB>
+__device__ __forceinline__ void bwd_coeff_one(const float* __restrict__ Ls, const int (&colbase)[KCfg<KB>::NR][4],
+                                              const Chol<KB>& S, float (&cf)[KCfg<KB>::NR][16]) {
+    constexpr int prow = 16 * PB + T;
+    const float v = Ls[colbase[RR][(T >> 2) & 3] + prow * 16];
+    cf[RR][T] = select_lanes<lanes_below<prow, RR>()>(v * S.di[RR], 0.f);
+    if constexpr (T + 1 < 16) bwd_coeff_one<KB, RR, T + 1, PB>(Ls, colbase, S, cf);
+    else if constexpr (RR + 1 < KCfg<KB>::NR) bwd_coeff_one<KB, RR + 1, 0, PB>(Ls, colbase, S, cf);
+}
+template <int KB, int PB0>
+__device__ __forceinline__ void bwd_coeffs(const float* __restrict__ Ls, const int (&colbase)[KCfg<KB>::NR][4],
+                                           const Chol<KB>& S, float (&cf)[KCfg<KB>::NR][16],
+                                           std::integral_constant<int, PB0>, int pb) {
+    // pb is a compile-time constant at every call site (unrolled loop); dispatch it to the template
+    if (pb == PB0) bwd_coeff_one<KB, 0, 0, PB0>(Ls, colbase, S, cf);
+    else if constexpr (PB0 + 1 < KB) bwd_coeffs<KB>(Ls, colbase, S, cf, std::integral_constant<int, PB0 + 1>{}, pb);
+}
+
 // L^T x = y with L in LDS (block columns).  Lane (+64 rr) owns unknown i = lane + 64 rr and
 // reads its column L[p][i], p > i, 16 rows at a time.
 template <int KB>
@@ -425,16 +446,7 @@ __device__ __forceinline__ void backward_solve(const float* __restrict__ Ls, con
 #pragma unroll
     for (int pb = KB - 1; pb >= 0; --pb) {
         float cf[NR][16];
-#pragma unroll
-        for (int rr = 0; rr < NR; ++rr) {
-            const int i = lane + 64 * rr;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int prow = 16 * pb + t;
-                const float v = Ls[colbase[rr][(t >> 2) & 3] + prow * 16];
-                cf[rr][t] = (prow > i) ? v * S.di[rr] : 0.f;
-            }
-        }
+        bwd_coeffs<KB>(Ls, colbase, S, cf, std::integral_constant<int, 0>{}, pb);
 #pragma unroll
         for (int t = 15; t >= 0; --t) {
             const int prow = 16 * pb + t;
