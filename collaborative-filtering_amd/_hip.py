@@ -16,7 +16,7 @@ SPLIT_CHUNK = 4096          # ALS_SPLIT_CHUNK
 MAX_K = 160                 # ALS_MAX_K
 
 EXPORTS = ("als_version", "als_padded_k", "als_perm_index", "als_partial_slot_bytes",
-           "als_row_solve", "als_gs_sweep", "als_gs_sweep_levels", "als_gs_sweep_dataflow", "als_residual_stats", "als_w_normal_equations", "als_spd_solve_workspace_bytes", "als_spd_solve_f64", "als_sum_pairs", "als_sumsq_partials",
+           "als_row_solve", "als_gs_sweep", "als_gs_sweep_levels", "als_gs_sweep_dataflow", "als_residual_stats", "als_w_normal_equations", "als_spd_solve_workspace_bytes", "als_spd_solve_f64", "als_item_stats", "als_sum_pairs", "als_sumsq_partials",
            "als_sumsq", "als_compose_z", "als_predict_at", "als_predict_dense")
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -97,6 +97,7 @@ def load():
                                        _vp, _i64, _vp, _vp, _vp]
     lib.als_w_normal_equations.argtypes = [C.POINTER(WParams), _vp]
     lib.als_sumsq_partials.restype = C.c_int
+    lib.als_item_stats.argtypes = [C.c_int, C.c_int, _i64, _i64] + [_vp] * 11
     lib.als_spd_solve_workspace_bytes.argtypes = [_i64]
     lib.als_spd_solve_f64.argtypes = [_i64, _vp, _i64, _vp, C.c_double, _vp, _vp, _vp, _vp]
     lib.als_sumsq.argtypes = [_vp, _i64, _vp, _vp, _vp]

@@ -413,11 +413,18 @@ class _Engine:
         #     sums of an iteration follow in closed form from what the V-step already holds
         self.fused_stats = ((not self.feat_names) and hasattr(backend, "sum_pairs")
                             and (self.ld <= 64 or not self.use_graph or getattr(self, "gs_dataflow", False)))
-        if self.fused_stats:
+        # with features Z != V: the same sums follow per item from the V-step's Gram / rhs / column sums
+        # and the final Z (als_item_stats), again without a pass over the ratings
+        self.fused_feat_stats = (bool(self.feat_names) and hasattr(backend, "item_stats")
+                                 and hasattr(backend, "sum_pairs"))
+        if self.fused_stats or self.fused_feat_stats:
             self.stat_rows = torch.zeros(n_pad, 2, dtype=f32, device=device)
-            if self.use_graph:
+            if self.use_graph or self.fused_feat_stats:
                 self.sumr2 = torch.zeros(n_pad, dtype=f32, device=device)
+            if self.use_graph:
                 self.lam_eff = (self.lam_v_row + np.float32(EPS) + self.diag_extra).contiguous()
+        if self.fused_feat_stats and not self.use_graph:
+            self.sumr = torch.zeros(n_pad, dtype=f32, device=device)
         # --- stats scratch
         self.stats = torch.zeros(2, dtype=f64, device=device)
         self.ss = torch.zeros(4, dtype=f64, device=device)
@@ -531,14 +538,17 @@ class _Engine:
             with self._tick("row_solve_item"):
                 self.be.row_solve(diag_extra=None, X_out=self.V, bias_out=self.b_i, factor_out=None,
                                   rhs_out=self.rhs_out if want_gram else None,
-                                  colsum_out=self.colsum_out if want_gram else None, sumr_out=None,
+                                  colsum_out=self.colsum_out if want_gram else None,
+                                  sumr_out=self.sumr if self.fused_feat_stats else None,
+                                  sumr2_out=self.sumr2 if self.fused_feat_stats else None,
                                   stat_out=self.stat_rows if self.fused_stats else None, **common)
         else:
             # phase A (parallel): Gram, rhs, Cholesky factor of every item of the shard
             with self._tick("row_solve_item"):
                 self.be.row_solve(diag_extra=self.diag_extra, X_out=None, bias_out=None,
                                   factor_out=self.factor, rhs_out=self.rhs_out, colsum_out=self.colsum_out,
-                                  sumr_out=self.sumr, sumr2_out=self.sumr2 if self.fused_stats else None,
+                                  sumr_out=self.sumr,
+                                  sumr2_out=self.sumr2 if (self.fused_stats or self.fused_feat_stats) else None,
                                   **common)
             # phase B (sequential in levels): Gauss-Seidel sweep with live V (:458)
             if self.multi and self.gs_mode == "exact":
@@ -710,6 +720,12 @@ class _Engine:
         with self._tick("residual_stats"):
             if self.fused_stats:        # per-item (sum d, sum d^2) written by the V-step / the sweep
                 self.be.sum_pairs(self.stat_rows, self.stats)
+            elif self.fused_feat_stats:  # per-item closed form with the final Z (features present)
+                self.be.item_stats(k=self.k, ld=self.ld, item_begin=self.ib, item_end=self.ie, gram=self.gram,
+                                   rhs=self.rhs_out, colsum=self.colsum_out, sumr=self.sumr, sumr2=self.sumr2,
+                                   indptr=self.csc.indptr, Z=self.Z, b_new=self.b_i, b_old=self.b_i_prev,
+                                   stat_out=self.stat_rows)
+                self.be.sum_pairs(self.stat_rows, self.stats)
             else:
                 self.be.residual_stats(k=self.k, ld=self.ld, side=self.csr, U=self.U, Z=self.Z, b_u=self.b_u,
                                        b_i=self.b_i, mu=self.mu, tasks=self.utasks, out=self.stats)
@@ -731,8 +747,9 @@ class _Engine:
         # Z is current here: stats_step recomposes it after every V / W update
         self.user_step()
         do_w = has_feat and ((it % md.update_w_every == 0) or (it == n_iters - 1))       # :468
-        b_i_old = self.b_i.clone() if do_w else None
-        self.item_step(want_gram=do_w)
+        b_i_old = self.b_i.clone() if (do_w or self.fused_feat_stats) else None
+        self.b_i_prev = b_i_old
+        self.item_step(want_gram=do_w or self.fused_feat_stats)
         if do_w:
             with self._tick("w_step"):
                 self.w_step(b_i_old)

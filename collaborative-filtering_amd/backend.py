@@ -176,6 +176,13 @@ class HipBackend:
             _p(mu), _p(tasks.tasks), tasks.ntasks, _p(self._stats_partials), _p(out), self._stream()),
             "als_residual_stats")
 
+    def item_stats(self, *, k, ld, item_begin, item_end, gram, rhs, colsum, sumr, sumr2, indptr, Z, b_new, b_old,
+                   stat_out):
+        """Per-item closed-form residual sums when Z != V (als_item_stats)."""
+        self._check(self.lib.als_item_stats(k, ld, int(item_begin), int(item_end), _p(gram), _p(rhs), _p(colsum),
+                                            _p(sumr), _p(sumr2), _p(indptr), _p(Z), _p(b_new), _p(b_old),
+                                            _p(stat_out), self._stream()), "als_item_stats")
+
     def sum_pairs(self, x: torch.Tensor, out: torch.Tensor):
         """out[0:2] = column sums of x viewed as [n, 2] (fp64, deterministic)."""
         part = torch.empty(2 * self._sumsq_partials.numel(), dtype=torch.float64, device=self.device)

@@ -57,6 +57,37 @@ __device__ __forceinline__ void lds_matvec(const float* S, const int (&p)[KCfg<K
     }
 }
 
+// Up to KP = 112 an item's Gram is staged once as a full symmetric LDS image (coalesced row loads of the
+// lower blocks, mirrored on the way in; diagonal blocks from their lower triangle, as gsym does); matrix-
+// vector products then read LDS rows instead of half-transposed global memory.
+template <int KB>
+constexpr bool gram_fits_lds() { return KCfg<KB>::KP * (KCfg<KB>::KP + 1) * 4 <= 64 * 1024; }
+
+template <int KB>
+__device__ __forceinline__ void stage_gram_lds(const float* __restrict__ G, float* __restrict__ S, int lane) {
+    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR;
+    float gv[NR][16];
+    for (int r0 = 0; r0 < KP; r0 += 16) {
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = r0 + u, c = lane + 64 * rr;
+                const bool ok = c < 16 * (r / 16 + 1) && !(c / 16 == r / 16 && c > r);
+                gv[rr][u] = ok ? G[r * KP + c] : 0.f;
+            }
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int r = r0 + u, c = lane + 64 * rr;
+                const bool ok = c < 16 * (r / 16 + 1) && !(c / 16 == r / 16 && c > r);
+                if (ok) { S[r * (KP + 1) + c] = gv[rr][u]; S[c * (KP + 1) + r] = gv[rr][u]; }
+            }
+    }
+    wave_lds_sync();
+}
+
 template <int KB>
 __global__ __launch_bounds__(64)
 void k_w_item_vectors(int k, int64_t i0, int64_t i1, const float* __restrict__ gram,
@@ -70,33 +101,9 @@ void k_w_item_vectors(int k, int64_t i0, int64_t i1, const float* __restrict__ g
     if (i >= i1) return;
     const int lane = threadIdx.x;
     const float* G = gram + i * KP * KP;
-    // Up to KP = 112 the item's Gram is staged once as a full symmetric LDS image (coalesced row loads of
-    // the lower blocks, mirrored on the way in; diagonal blocks from their lower triangle, as gsym does);
-    // the nfeat + 1 products then read LDS rows instead of half-transposed global memory.
-    constexpr bool STAGE = KP * (KP + 1) * 4 <= 64 * 1024;
+    constexpr bool STAGE = gram_fits_lds<KB>();
     __shared__ float S[STAGE ? KP * (KP + 1) : 1];
-    if constexpr (STAGE) {
-        float gv[NR][16];
-        for (int r0 = 0; r0 < KP; r0 += 16) {
-#pragma unroll
-            for (int rr = 0; rr < NR; ++rr)
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int r = r0 + u, c = lane + 64 * rr;
-                    const bool ok = c < 16 * (r / 16 + 1) && !(c / 16 == r / 16 && c > r);
-                    gv[rr][u] = ok ? G[r * KP + c] : 0.f;
-                }
-#pragma unroll
-            for (int rr = 0; rr < NR; ++rr)
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int r = r0 + u, c = lane + 64 * rr;
-                    const bool ok = c < 16 * (r / 16 + 1) && !(c / 16 == r / 16 && c > r);
-                    if (ok) { S[r * (KP + 1) + c] = gv[rr][u]; S[c * (KP + 1) + r] = gv[rr][u]; }
-                }
-        }
-        wave_lds_sync();
-    }
+    if constexpr (STAGE) stage_gram_lds<KB>(G, S, lane);
     int p[NR], col[NR];
     float z[NR], gz[NR];
 #pragma unroll
@@ -124,6 +131,53 @@ void k_w_item_vectors(int k, int64_t i0, int64_t i1, const float* __restrict__ g
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr)
             if (lane + 64 * rr < KP) H[((int64_t)f * nrows_h + i) * KP + p[rr]] = g[rr] + gx[rr];
+    }
+}
+
+// Closed-form residual sums of one item when Z != V (features present), one wave per item:
+//   d = rho - b_new - u . z_i over the item's ratings, rho = r - mu - b_u
+//   sum d   = sum rho - n b_new - z . (U_i^T 1)
+//   sum d^2 = sum (rho - b_new)^2 - 2 z . U_i^T (rho - b_new) + z^T G_i z
+// from the V-step by-products (G_i, U_i^T (rho - b_old), U_i^T 1, sum rho, sum rho^2).  fp64 from the dot
+// products on.  Replaces the standalone pass over the ratings (k_residual_stats) in fits with features.
+template <int KB>
+__global__ __launch_bounds__(64)
+void k_item_stats(int64_t i0, int64_t i1, int ld, const float* __restrict__ gram, const float* __restrict__ rhs,
+                  const float* __restrict__ colsum, const float* __restrict__ sumr, const float* __restrict__ sumr2,
+                  const int64_t* __restrict__ indptr, const float* __restrict__ Z, const float* __restrict__ b_new,
+                  const float* __restrict__ b_old, float* __restrict__ stat_out) {
+    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR;
+    const int64_t i = i0 + blockIdx.x;
+    if (i >= i1) return;
+    const int lane = threadIdx.x;
+    const float* G = gram + i * KP * KP;
+    constexpr bool STAGE = gram_fits_lds<KB>();
+    __shared__ float S[STAGE ? KP * (KP + 1) : 1];
+    if constexpr (STAGE) stage_gram_lds<KB>(G, S, lane);
+    int p[NR];
+    float z[NR], gz[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        p[rr] = min(lane + 64 * rr, KP - 1);
+        z[rr] = (lane + 64 * rr < KP) ? Z[i * ld + perm_to_col<KB>(p[rr])] : 0.f;
+    }
+    if constexpr (STAGE) lds_matvec<KB>(S, p, z, gz); else gsym_matvec<KB>(G, p, z, gz);
+    double zgz = 0.0, zr = 0.0, zc = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr)
+        if (lane + 64 * rr < KP) {
+            zgz += (double)z[rr] * (double)gz[rr];
+            zr += (double)z[rr] * (double)rhs[i * KP + p[rr]];
+            zc += (double)z[rr] * (double)colsum[i * KP + p[rr]];
+        }
+    zgz = wave_sum_d(zgz); zr = wave_sum_d(zr); zc = wave_sum_d(zc);
+    if (lane == 0) {
+        const double n = (double)(indptr[i + 1] - indptr[i]);
+        const double b = b_new[i], bo = b_old[i], sr = sumr[i], sr2 = sumr2[i];
+        const double s1 = sr - n * b - zc;
+        const double s2 = (sr2 - 2.0 * b * sr + n * b * b) - 2.0 * (zr + (bo - b) * zc) + zgz;
+        stat_out[2 * i] = (float)s1;
+        stat_out[2 * i + 1] = (float)s2;
     }
 }
 
@@ -319,5 +373,36 @@ extern "C" int als_w_normal_equations(const als_w_params* p, void* stream) {
         case 9: return launch_w<9>(p, st);
         case 10: return launch_w<10>(p, st);
     }
+    return ALS_E_BADK;
+}
+
+namespace {
+template <int KB>
+int launch_item_stats(int64_t i0, int64_t i1, int ld, const float* gram, const float* rhs, const float* colsum,
+                      const float* sumr, const float* sumr2, const int64_t* indptr, const float* Z,
+                      const float* b_new, const float* b_old, float* stat_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_item_stats<KB>, dim3((unsigned)(i1 - i0)), dim3(64), 0, st, i0, i1, ld, gram, rhs, colsum,
+                       sumr, sumr2, indptr, Z, b_new, b_old, stat_out);
+    return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
+}
+}  // namespace
+
+extern "C" int als_item_stats(int k, int ld, int64_t item_begin, int64_t item_end, const float* gram,
+                              const float* rhs, const float* colsum, const float* sumr, const float* sumr2,
+                              const int64_t* indptr, const float* Z, const float* b_new, const float* b_old,
+                              float* stat_out, void* stream) {
+    const int kp = als_padded_k(k);
+    if (kp < 0) return ALS_E_BADK;
+    if (ld != kp || item_end < item_begin || !gram || !rhs || !colsum || !sumr || !sumr2 || !indptr || !Z ||
+        !b_new || !b_old || !stat_out)
+        return ALS_E_BADARG;
+    if (item_end == item_begin) return 0;
+    hipStream_t st = (hipStream_t)stream;
+#define ALS_IS(KBV) case KBV: return launch_item_stats<KBV>(item_begin, item_end, ld, gram, rhs, colsum, sumr, sumr2, \
+                                                           indptr, Z, b_new, b_old, stat_out, st)
+    switch (ld / 16) {
+        ALS_IS(1); ALS_IS(2); ALS_IS(3); ALS_IS(4); ALS_IS(5); ALS_IS(6); ALS_IS(7); ALS_IS(8); ALS_IS(9); ALS_IS(10);
+    }
+#undef ALS_IS
     return ALS_E_BADK;
 }

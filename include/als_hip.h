@@ -259,6 +259,15 @@ size_t als_spd_solve_workspace_bytes(int64_t N);
 int als_spd_solve_f64(int64_t N, const double* A, int64_t lda, const double* b, double diag_add,
                       double* x, void* workspace, int32_t* status, void* stream);
 
+/* Closed-form residual sums per item when Z != V (fits with features), replacing the pass over the
+ * ratings of scripts/als.py:505-511: stat_out[i] = (sum d, sum d^2), d = r - mu - b_u - b_new[i] - u.Z[i],
+ * from the als_row_solve by-products of this iteration's V-step (gram_out, rhs_out, colsum_out, sumr_out,
+ * sumr2_out - rhs formed with b_old) over items [item_begin, item_end).  Z: [n][ld] storage order. */
+int als_item_stats(int k, int ld, int64_t item_begin, int64_t item_end, const float* gram,
+                   const float* rhs, const float* colsum, const float* sumr, const float* sumr2,
+                   const int64_t* indptr, const float* Z, const float* b_new, const float* b_old,
+                   float* stat_out, void* stream);
+
 /* out[0] = sum_i x[2i], out[1] = sum_i x[2i+1] in fp64 (reduction of stat_out).
  * partials: scratch of 2*als_sumsq_partials() doubles. */
 int als_sum_pairs(const float* x, int64_t npairs, double* partials, double* out, void* stream);

@@ -186,3 +186,16 @@ def test_cfg3_full_size_w_step_is_the_ridge_optimum():
         # the normal equations are assembled from fp32 item Grams (exact 3-way bf16 products, fp32 sums)
         assert rel < 2e-5, (f, rel)
         assert float((W_new - W_old[f]).norm() / W_old[f].norm()) > 1e-3     # the step did move W
+    # ---- statistics with features: per-item closed form (als_item_stats) vs the pass over the ratings ------
+    eng.b_i_prev = b_i_old                                # what eng.iteration() records before its V-step
+    eng.stats_step(1)
+    assert eng.fused_feat_stats
+    fused = eng.stats.clone()
+    alone = torch.zeros(2, dtype=f64, device=dev)
+    # stats_step has already moved mu; the standalone pass must see the mu the closed form was taken at
+    mu_before = eng.mu - fused[0] / nnz
+    eng.be.residual_stats(k=eng.k, ld=eng.ld, side=eng.csr, U=eng.U, Z=eng.Z, b_u=eng.b_u, b_i=eng.b_i,
+                          mu=mu_before, tasks=eng.utasks, out=alone)
+    f_, a_ = fused.cpu().numpy(), alone.cpu().numpy()
+    assert abs(f_[0] - a_[0]) / nnz < 2e-6
+    assert abs(np.sqrt(f_[1] / nnz) - np.sqrt(a_[1] / nnz)) < 2e-6

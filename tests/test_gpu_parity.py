@@ -184,6 +184,30 @@ def test_fused_statistics_equal_the_standalone_pass():
     assert abs(a.mu - b.mu) <= 3e-6
 
 
+@pytest.mark.parametrize("name", ["g4_feat_uw2", "g4_feat_uw5"])
+def test_feature_statistics_closed_form_equals_the_standalone_pass(name):
+    """Fits with features: mu / RMSE from the per-item closed form (als_item_stats: item Gram, rhs, column
+    sums and the final Z) against the standalone pass over the ratings (als_residual_stats)."""
+    _cuda()
+    g = Golden(name)
+    r, c, v = g.train
+    a = _model_for(g).fit_coo(r, c, v, (g.m, g.n), features=g.features, tol=None, verbose=0)
+    assert a._eng.fused_feat_stats and not a._eng.fused_stats
+    import collaborative_filtering_amd.als as A
+    orig = A._Engine.stats_step
+
+    def unfused(self, it):
+        self.fused_feat_stats = False
+        return orig(self, it)
+    A._Engine.stats_step = unfused
+    try:
+        b = _model_for(g).fit_coo(r, c, v, (g.m, g.n), features=g.features, tol=None, verbose=0)
+    finally:
+        A._Engine.stats_step = orig
+    np.testing.assert_allclose(a.history["train_rmse"], b.history["train_rmse"], atol=3e-6, rtol=0)
+    assert abs(a.mu - b.mu) <= 3e-6
+
+
 def test_cfg2_full_size_against_oracle():
     """BASELINE.json configs[1] at full size (6040 x 3706, 1M ratings, k = 32, explicit bias lambdas):
     three iterations of the HIP path against the oracle on the same seeded input."""
