@@ -43,6 +43,9 @@ SIZES = {   # name: (m, n, nnz, k)   - cfg4 is the headline; the others are diag
     "cfg4": (1_000_000, 100_000, 100_000_000, 64),
     "cfg4-small": (100_000, 10_000, 5_000_000, 64),       # rehearsal size
     "cfg5-small": (200_000, 20_000, 10_000_000, 128),     # BASELINE configs[4] shape / 50: full model, k = 128
+    "k80": (100_000, 10_000, 5_000_000, 80),              # rehearsal size at other ranks (KB = 5, 6, 10)
+    "k96": (100_000, 10_000, 5_000_000, 96),
+    "k160": (100_000, 10_000, 5_000_000, 160),
     "tiny": (4_000, 1_500, 150_000, 64),
 }
 

@@ -99,7 +99,7 @@ struct KCfg {
     static_assert(lcol_off(KB) == NACC * 256, "the L image and a full accumulator set have the same size");
     // waves per workgroup / minimum waves per SIMD asked of the register allocator
     static constexpr int WPW = (KB <= 4) ? 4 : (KB <= 6 ? 2 : 1);
-    static constexpr int MINW = (KB <= 4) ? 3 : 1;
+    static constexpr int MINW = (KB <= 4) ? 3 : (KB <= 6 ? 2 : 1);
     static constexpr int SLOT_ITEMS = NACC * 4 + 2 * KB + 2;  // per-lane floats of a partial
     // gather steps (4 ratings each) staged in registers at a time
     static constexpr int GS = (KB <= 8) ? 8 : 4;

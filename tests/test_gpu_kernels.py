@@ -35,7 +35,7 @@ def _pad(A, ld, extra_rows=0):
 
 
 @pytest.mark.parametrize("gram", ["bf16x3", "f32"])
-@pytest.mark.parametrize("k", [1, 16, 32, 50, 64, 128])
+@pytest.mark.parametrize("k", [1, 16, 32, 50, 64, 80, 96, 112, 128, 160])
 def test_row_solve_against_numpy(k, gram):
     torch, layout, side_dev, tasks_dev, be, dev = _env(gram)
     ncols = 9000
@@ -101,7 +101,7 @@ def test_row_solve_against_numpy(k, gram):
                                    atol=1e-5 * max(np.max(np.abs(ref)), 1e-6))
 
 
-@pytest.mark.parametrize("k", [16, 64, 128])
+@pytest.mark.parametrize("k", [16, 64, 80, 96, 128, 160])
 def test_factor_mode_and_gs_level(k):
     """factor-only als_row_solve + als_gs_sweep on one level == direct solve with the graph term."""
     torch, layout, side_dev, tasks_dev, be, dev = _env()
@@ -172,7 +172,7 @@ def test_factor_mode_and_gs_level(k):
         assert abs(bn[i] - bref) <= 2e-4 * max(1.0, abs(bref))
 
 
-@pytest.mark.parametrize("k", [1, 16, 50, 64, 128])
+@pytest.mark.parametrize("k", [1, 16, 50, 64, 96, 128, 160])
 def test_stats_predict_compose(k):
     torch, layout, side_dev, tasks_dev, be, dev = _env()
     m, n = 300, 500

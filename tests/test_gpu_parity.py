@@ -252,7 +252,7 @@ def test_features_mid_size_against_oracle():
     _close(model.V, o.V, what="V")
 
 
-@pytest.mark.parametrize("k", [16, 50, 128])
+@pytest.mark.parametrize("k", [16, 50, 80, 128, 150])
 def test_graph_sweep_other_k_against_oracle(k):
     """The dataflow Laplacian sweep for k != 64 (register solve for k <= 64, streamed solve above),
     with a precomputed graph and no features, against the oracle."""
