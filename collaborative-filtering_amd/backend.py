@@ -9,6 +9,7 @@ can be exercised on CPU under gloo with a stand-in solver living in tests/.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -38,7 +39,7 @@ class HipBackend:
                                            device=device)
         self._stats_partials: Optional[torch.Tensor] = None
         self._spd_ws: Optional[torch.Tensor] = None
-        self.ablate = int(__import__('os').environ.get('ALS_ABLATE', '0'))   # diagnostics only
+        self.ablate = int(os.environ.get("ALS_ABLATE", "0"))   # phase ablation of als_row_solve (profiles/ablate.sh)
 
     # -- helpers -------------------------------------------------------------
     def _stream(self):

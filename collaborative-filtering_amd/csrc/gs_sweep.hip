@@ -152,18 +152,19 @@ void k_gs_level(const als_gs_sweep_params P) {
 // ---------------------------------------------------------------------------
 // K2': the whole sweep as ONE persistent, synchronisation-free launch.
 //
-// Items are listed in (level, id) order and dealt round-robin to `nwaves` co-resident waves
-// (one workgroup per CU); each wave walks its items in that order.  An item waits only for the
-// neighbours it really depends on (j < i and swept - flagged by the sign bit of `Sw`), by polling
-// their done-flags; there is no level barrier.  Progress: the earliest unfinished item in the
-// global order has all dependencies finished and is the next item of a resident wave.
+// Items are listed in (level, id) order and dealt round-robin to `nwaves` co-resident waves; each wave
+// walks its items in that order.  An item waits only for the neighbours it really depends on (j < i and
+// swept - flagged by the sign bit of `Sw`); there is no level barrier.  Progress: the earliest unfinished
+// item in the global order has all dependencies finished and is the next item of a resident wave.
 //
-// Cross-CU / cross-XCD visibility follows cdna_hip_programming.md Guideline 16, form R1: every
-// store of a handed-off V row and of its flag is an agent-scope (sc1, write-through) store, the
-// storing wave drains them (s_waitcnt vmcnt(0)) before the flag, and EVERY load of V rows and
-// flags in this kernel is an agent-scope (sc1, L1-bypassing) load.  Flags hold the sweep number,
-// so they never need resetting.  Every spin is bounded: on timeout the wave raises `err` and
-// carries on with whatever it read (wrong numbers, no hang) - the host turns it into an error.
+// Hand-off: solved rows travel through the publication buffer `pub` (same shape as V), every word of which
+// the launcher resets to GS_SENTINEL.  A producer stores its row there with agent-scope (sc1, write-
+// through) stores; a consumer reads the words it needs with agent-scope (L1-bypassing) loads and polls
+// until none is the sentinel.  Data and "ready" travel in the same 4-byte word (cdna_hip_programming.md,
+// data-tagged granules), so no flag, no drain before a flag and no ordering between words is needed; V
+// itself is written with plain stores for the launches that follow.  Every spin is bounded: on timeout the
+// wave raises `err` and carries on with whatever it read (wrong numbers, no hang) - the host turns it
+// into an error.
 // ---------------------------------------------------------------------------
 // "not yet published" marker of the dataflow sweep: a quiet NaN with a payload no arithmetic produces
 constexpr unsigned GS_SENTINEL = 0x7fc0dea1u;

@@ -211,13 +211,12 @@ void k_w_accumulate(int64_t i0, int64_t i1, int nchunks, const float* __restrict
     const int64_t cb = i0 + chunk * per, ce = min(i1, cb + per);
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int rr = t >> 4, cc = t & 15;
-    int off[NACC], offT[NACC];                     // element offsets inside G_i; offT: canonical (lower) twin
+    int offT[NACC];                                // element offsets inside G_i (diagonal blocks: lower twin)
 #pragma unroll
     for (int q = 0; q < NACC; ++q) {
         int I, J;
         lower_block(q, I, J);
-        off[q] = (16 * I + rr) * KP + 16 * J + cc;
-        offT[q] = (I == J && rr < cc) ? (16 * I + cc) * KP + 16 * J + rr : off[q];
+        offT[q] = (I == J && rr < cc) ? (16 * I + cc) * KP + 16 * J + rr : (16 * I + rr) * KP + 16 * J + cc;
     }
     double acc[NACC];
 #pragma unroll
