@@ -185,7 +185,7 @@ struct DfCfg {   // k <= 64: factor column in registers, 4 waves per workgroup; 
 };
 
 template <int KB>
-__global__ __launch_bounds__(64 * DfCfg<KB>::WPW)
+__global__ __launch_bounds__(64 * DfCfg<KB>::WPW, (KB <= 4) ? 2 : 1)
 void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, float* pub,
                    int32_t* err, int64_t nitems, int nwaves) {
     using C = KCfg<KB>;
@@ -414,16 +414,24 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
 template <int KB>
 int launch_gs_dataflow(const als_gs_sweep_params* p, const int32_t* Sw, float* pub,
                        int32_t* err, int64_t nitems, hipStream_t st) {
-    // Every wave of the launch must be co-resident on the 256-CU part.  k <= 64: two 4-wave workgroups
-    // per CU (<= 256 VGPRs, no LDS: 2 waves per SIMD fit) = 2048 waves.  k > 64: one-wave workgroups,
-    // as many per CU as their LDS images fit into 160 KB (2 at k = 128, 1 at k = 160), at most 8.
+    // Every wave of the launch must be co-resident (a non-resident workgroup would never start while the
+    // resident ones wait for its items): the grid is sized from the occupancy the runtime reports for this
+    // kernel - registers and LDS included - times the number of CUs, capped at 8 waves per CU.
+    // (k <= 64: 4-wave workgroups, 2 per CU under the launch bound; k > 64: one-wave workgroups, as many per
+    // CU as their LDS images fit.)
     constexpr int WPW = DfCfg<KB>::WPW;
-    int per_cu = 2;
-    if (KB > 4) {
-        per_cu = (160 * 1024) / (int)(DfCfg<KB>::IMG * sizeof(float));
-        if (per_cu > 8) per_cu = 8;
+    static int per_cu = 0, ncu = 0;
+    if (per_cu == 0) {
+        int dev = 0, nb = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gs_dataflow<KB>, 64 * WPW, 0) != hipSuccess || nb < 1)
+            return ALS_E_LAUNCH;
+        ncu = prop.multiProcessorCount;
+        per_cu = nb * WPW > 8 ? 8 / WPW : nb;
+        if (per_cu < 1) per_cu = 1;
     }
-    int nwg = 256 * per_cu;
+    int nwg = ncu * per_cu;
     if ((int64_t)nwg * WPW > nitems) nwg = (int)((nitems + WPW - 1) / WPW);
     if (nwg < 1) return 0;
     hipLaunchKernelGGL(k_gs_dataflow<KB>, dim3(nwg), dim3(64 * WPW), 0, st, *p, Sw, pub, err, nitems, nwg * WPW);
