@@ -57,11 +57,11 @@ __device__ __forceinline__ void lds_matvec(const float* S, const int (&p)[KCfg<K
     }
 }
 
-// Up to KP = 112 an item's Gram is staged once as a full symmetric LDS image (coalesced row loads of the
+// An item's Gram is staged once as a full symmetric LDS image (coalesced row loads of the
 // lower blocks, mirrored on the way in; diagonal blocks from their lower triangle, as gsym does); matrix-
 // vector products then read LDS rows instead of half-transposed global memory.
 template <int KB>
-constexpr bool gram_fits_lds() { return KCfg<KB>::KP * (KCfg<KB>::KP + 1) * 4 <= 64 * 1024; }
+constexpr bool gram_fits_lds() { return KCfg<KB>::KP * (KCfg<KB>::KP + 1) * 4 <= 160 * 1024; }
 
 template <int KB>
 __device__ __forceinline__ void stage_gram_lds(const float* __restrict__ G, float* __restrict__ S, int lane) {
@@ -72,9 +72,9 @@ __device__ __forceinline__ void stage_gram_lds(const float* __restrict__ G, floa
         for (int rr = 0; rr < NR; ++rr)
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const int r = r0 + u, c = lane + 64 * rr;
-                const bool ok = c < 16 * (r / 16 + 1) && !(c / 16 == r / 16 && c > r);
-                gv[rr][u] = ok ? G[r * KP + c] : 0.f;
+                // unconditional (address clamped into the row): 16 NR independent loads in flight; what lies
+                // outside the lower blocks is dropped below
+                gv[rr][u] = G[(r0 + u) * KP + min(lane + 64 * rr, KP - 1)];
             }
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr)
