@@ -220,6 +220,8 @@ def main():
                     help="Laplacian sweep with several ranks: exact (default; shards in rank order), block, levels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="debug only; not a valid headline run")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="replay iterations as captured HIP graphs (no per-phase timing; for launch-bound sizes)")
     ap.add_argument("--gram", default="bf16x3", choices=["bf16x3", "f32"],
                     help="how K1 forms the Gram: exact 3-way bf16 split on the bf16 matrix cores (fp32 "
                          "accumulate, fp32-level accuracy) or v_mfma_f32 on the raw floats")
@@ -286,7 +288,7 @@ def main():
                     graph=(GraphConfig(alpha=0.5, sim=GraphSimConfig(source="precomputed", topk=50))
                            if S is not None else GraphConfig()))
     model = ALS(cfg, lambda_w={"genres": 5.0, "years": 10.0} if features else None,
-                device=dev, gs_mode=args.gs_mode, gram=args.gram)
+                device=dev, gs_mode=args.gs_mode, gram=args.gram, hip_graph=args.hip_graph)
     eng = model.prepare_csr(csr, csc, (m, n), features=features, S=S)
     if features:
         eng.be.compose_z(eng.V, eng.Xcat, eng.Wcat, eng.Z)
@@ -301,7 +303,7 @@ def main():
     for it in range(args.warmup):
         eng.iteration(it, n_total)
     barrier()
-    eng.timers = []
+    eng.timers = None if args.hip_graph else []       # event pairs cannot be recorded inside a captured graph
     t0 = time.perf_counter()
     for it in range(args.warmup, n_total):
         eng.iteration(it, n_total)
@@ -315,7 +317,7 @@ def main():
 
     # per-kernel times from the events recorded on the launch stream
     phase = {}
-    for name, a, b in eng.timers:
+    for name, a, b in (eng.timers or []):
         phase.setdefault(name, []).append(a.elapsed_time(b))
     eng.timers = None
     hist = eng.hist[: n_total].cpu().numpy()
@@ -331,7 +333,7 @@ def main():
         rows_i = eng.ie - eng.ib
         fl = (2 * k * k + 4 * k) * (nn_u + nn_i) + (k ** 3 / 3 + 2 * k * k) * (rows_u + rows_i)
         by = (4 * k + 12) * (nn_u + nn_i) + (4 * k + 12) * (rows_u + rows_i)
-        t_rs = 1e-3 * sum(rs_ms) / args.steps            # seconds per iteration in row-solve launches
+        t_rs = max(1e-3 * sum(rs_ms) / args.steps, 1e-12)   # seconds per iteration in row-solve launches
         n_launch = 2
         # Primary view: HBM.  With the Gram on the bf16 matrix cores the binding resources of this kernel are
         # the gather of 256-B factor rows (V-step launch: U does not fit the caches) and VALU issue (U-step
@@ -368,13 +370,13 @@ def main():
             "config": {"workload": f"{args.size}: {m} users x {n} items, {nnz} ratings, k={k}, bias + "
                                    f"graph-Laplacian (alpha=0.5, {0 if S is None else int(S[1].numel())} graph nnz)"
                                    + (" [BASELINE.json configs[3]]" if args.size == "cfg4" else ""),
-                       "gram": args.gram, "gs_mode": getattr(eng, "gs_mode", None), "gs_levels": (len(eng.sched.offsets) - 1)
+                       "gram": args.gram, "hip_graph": bool(args.hip_graph), "gs_mode": getattr(eng, "gs_mode", None), "gs_levels": (len(eng.sched.offsets) - 1)
                        if eng.use_graph else 0,
                        "parallelism": f"users/items sharded x{world}, all-gather of factor blocks",
                        "setup_s": t_setup},
             "phase_ms_per_step": {kk: sum(v) / args.steps for kk, v in phase.items()},
             "train_rmse": [float(x) for x in hist[:, 0]],
-            "roofline": roof,
+            "roofline": roof if not args.hip_graph else None,   # per-launch times need the eager path
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(eng)

@@ -9,7 +9,7 @@ per-row / per-rating step runs in the HIP kernels behind include/als_hip.h.
 
 Build-only additions (keyword arguments with defaults, so the reference
 signature is unchanged):
-  ALS(..., device=, backend=, gs_mode=, process_group=, gram=, graph_build=)
+  ALS(..., device=, backend=, gs_mode=, process_group=, gram=, graph_build=, hip_graph=)
   fit(..., S=)              precomputed similarity graph as CSR (ptr, idx, val)
   fit_coo(rows, cols, vals, shape, ...)   sparse-native entry for large inputs
   predict_at(flat_idx, ...) predictions at flat indices u*n+i without the
@@ -116,7 +116,7 @@ class ALS:
 
     def __init__(self, config: ALSConfig, lambda_w: Optional[Dict[str, float]] = None, *,
                  device=None, backend=None, gs_mode: Optional[str] = None, process_group=None,
-                 gram: Optional[str] = None, graph_build: str = "host") -> None:
+                 gram: Optional[str] = None, graph_build: str = "host", hip_graph: bool = False) -> None:
         if config is None:                                   # scripts/als.py:146-147
             raise ValueError("ALSConfig must be provided.")
         self.cfg = config
@@ -151,6 +151,7 @@ class ALS:
         if graph_build not in ("host", "device"):
             raise ValueError("graph_build must be 'host' (reference-identical, dense n x n) or 'device'")
         self._graph_build = graph_build
+        self._hip_graph = bool(hip_graph)          # replay iterations as captured HIP graphs (one rank only)
         self._eng: Optional[_Engine] = None
 
     # ------------------------------------------------------------------ fit
@@ -429,6 +430,8 @@ class _Engine:
         self.stats = torch.zeros(2, dtype=f64, device=device)
         self.ss = torch.zeros(4, dtype=f64, device=device)
         self.hist = torch.zeros(max(model.n_iters, 1), 6, dtype=f64, device=device)
+        self.hist_row = torch.zeros(6, dtype=f64, device=device)
+        self._graphs = {}
         self.iters_run = 0
 
     # ------------------------------------------------------------- helpers
@@ -460,6 +463,8 @@ class _Engine:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
 
     def _check_status(self):
+        if getattr(self, "w_bad", None) is not None and int(self.w_bad.item()):
+            raise np.linalg.LinAlgError("W-step normal equations of a feature are not positive definite")
         if getattr(self, "gs_dataflow", False) and int(self.gs_err.item()):
             raise RuntimeError("Gauss-Seidel dataflow sweep: a dependency wait timed out")
         bad = int(self.status.item())
@@ -645,6 +650,7 @@ class _Engine:
             self.feat_off_host = offs
             self.feat_off = torch.from_numpy(offs).to(self.dev)
             self.w_status = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            self.w_bad = torch.zeros(1, dtype=torch.int32, device=self.dev)      # sticky: read in _check_status
         self.be.w_item_vectors(k=k, ld=ld, item_begin=self.ib, item_end=self.ie, gram=self.gram,
                                rhs=self.rhs_out, colsum=self.colsum_out, V=self.V, b_new=self.b_i,
                                b_old=b_i_old, X=self.Xcat, feat_off=self.feat_off, W=self.Wcat, H=self.H)
@@ -657,9 +663,7 @@ class _Engine:
                 self._allreduce(A_full)
                 self._allreduce(B_full)
             x = self.be.spd_solve(A_full, B_full, float(md.lambda_w.get(f, 0.0)) + EPS, self.w_status)
-            bad = int(self.w_status.item())
-            if bad:
-                raise np.linalg.LinAlgError(f"W-step normal equations of feature '{f}' are not positive definite")
+            torch.maximum(self.w_bad, self.w_status, out=self.w_bad)     # no host round trip inside an iteration
             newW[f] = x.reshape(d, k)
         self.W64.update(newW)
         self._sync_wcat()
@@ -734,19 +738,28 @@ class _Engine:
             self.be.sumsq(t, self.ss[j:j + 1])
         mean_d = self.stats[0] / self.nnz
         self.mu += mean_d
-        h = self.hist[it]
+        h = self.hist_row                 # fixed address: the iteration can be replayed as a captured graph
         h[0] = torch.sqrt(torch.clamp(self.stats[1] / self.nnz - mean_d * mean_d, min=0.0))
         h[1:5] = torch.sqrt(self.ss)
         h[5] = self.mu[0]
+        if it is not None:
+            self.hist[it].copy_(h)
 
     # ------------------------------------------------------------------ run
     def iteration(self, it: int, n_iters: int):
         """One full ALS iteration (scripts/als.py:408-517), asynchronous on the stream."""
         md = self.model
-        has_feat = bool(self.feat_names)
+        do_w = bool(self.feat_names) and ((it % md.update_w_every == 0) or (it == n_iters - 1))   # :468
+        if self.model._hip_graph and not self.multi and self.timers is None and it > 0:
+            self._replay(do_w)
+            self.hist[it].copy_(self.hist_row)
+        else:
+            self._iteration_body(do_w, it)
+        self.iters_run = it + 1
+
+    def _iteration_body(self, do_w: bool, it):
         # Z is current here: stats_step recomposes it after every V / W update
         self.user_step()
-        do_w = has_feat and ((it % md.update_w_every == 0) or (it == n_iters - 1))       # :468
         b_i_old = self.b_i.clone() if (do_w or self.fused_feat_stats) else None
         self.b_i_prev = b_i_old
         self.item_step(want_gram=do_w or self.fused_feat_stats)
@@ -754,7 +767,20 @@ class _Engine:
             with self._tick("w_step"):
                 self.w_step(b_i_old)
         self.stats_step(it)
-        self.iters_run = it + 1
+
+    def _replay(self, do_w: bool):
+        """The iteration as a captured HIP graph (one per W-step / no-W-step variant): every launch of the
+        body - kernels of libals_hip.so on the capture stream, memsets, the few torch tensor ops - becomes a
+        graph node; later iterations replay it with one submission.  The first iteration always runs eagerly
+        (allocations, lazy initialisation, occupancy queries)."""
+        g = self._graphs.get(do_w)
+        if g is None:
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._iteration_body(do_w, None)
+            self._graphs[do_w] = g
+        g.replay()
 
     def run(self, tol, min_iters, verbose):
         md = self.model

@@ -297,3 +297,24 @@ def test_device_graph_build_in_fit():
                                                                      tol=None, verbose=0)
     np.testing.assert_allclose(a.history["train_rmse"], b.history["train_rmse"], atol=2e-6, rtol=0)
     np.testing.assert_allclose(a.V, b.V, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["g2_bias_pop", "g4_feat_uw2", "g5_graph_a0.5", "g6_early_stop"])
+def test_hip_graph_replay_is_bitwise_the_eager_fit(name):
+    """hip_graph=True: iterations after the first are replayed as captured HIP graphs (one per W-step /
+    no-W-step variant).  Same launches, same order: every result must be bitwise equal to the eager fit,
+    including the early-stopping iteration."""
+    _cuda()
+    g = Golden(name)
+    r, c, v = g.train
+    kw = dict(features=g.features or None, tol=g.cfg["tol"], min_iters=g.cfg["min_iters"], verbose=0)
+    a = _model_for(g).fit_coo(r, c, v, (g.m, g.n), **kw)
+    b = _model_for(g, hip_graph=True).fit_coo(r, c, v, (g.m, g.n), **kw)
+    assert b._eng._graphs, "no graph was captured"
+    assert len(a.history["train_rmse"]) == len(b.history["train_rmse"])
+    for key in ("U", "V", "b_u", "b_i"):
+        np.testing.assert_array_equal(getattr(a, key), getattr(b, key), err_msg=key)
+    np.testing.assert_array_equal(a.history["train_rmse"], b.history["train_rmse"])
+    assert a.mu == b.mu
+    for f in g.cfg["feats"]:
+        np.testing.assert_array_equal(a.W[f], b.W[f])
