@@ -654,9 +654,26 @@ void k_row_long(const als_row_solve_params P) {
     const als_long_row lr = P.long_rows[tid];
     RowAcc<KB> A;
     A.zero();
-    const float* ws = (const float*)P.workspace + (size_t)lr.slot0 * C::SLOT_ITEMS * 64;
-    for (int s = 0; s < lr.nslots; ++s) add_partial<KB>(A, ws + (size_t)s * C::SLOT_ITEMS * 64, lane);
+    // k_sum_slots has already folded the row's nslots partials into its first slot
+    add_partial<KB>(A, (const float*)P.workspace + (size_t)lr.slot0 * C::SLOT_ITEMS * 64, lane);
     finish_row<KB>(A, P, lr.row, lds_all + wave * C::LDS_FLOATS, lane);
+}
+
+// Partial normal equations of a split row, summed into the row's first slot: one thread per element, the
+// slots in ascending order (the order a single wave adding slot after slot would use - bitwise the same
+// sums), all elements of all long rows in parallel.  A single wave walking 40 slots of 41 KB (k = 128) with
+// a handful of loads in flight took milliseconds.
+template <int KB>
+__global__ __launch_bounds__(256)
+void k_sum_slots(const als_long_row* __restrict__ long_rows, float* __restrict__ workspace) {
+    constexpr int N = KCfg<KB>::SLOT_ITEMS * 64;
+    const als_long_row lr = long_rows[blockIdx.x];
+    const int e = blockIdx.y * 256 + threadIdx.x;
+    if (e >= N || lr.nslots < 2) return;
+    float* w0 = workspace + (size_t)lr.slot0 * N + e;
+    float acc = 0.f + w0[0];
+    for (int s = 1; s < lr.nslots; ++s) acc += w0[(size_t)s * N];
+    w0[0] = acc;
 }
 
 template <int KB>
@@ -670,6 +687,8 @@ int launch_row_solve(const als_row_solve_params* p, hipStream_t st) {
             hipLaunchKernelGGL((k_row_tasks<KB, 0>), dim3(grid), dim3(64 * C::WPW), 0, st, *p);
     }
     if (p->nlong > 0) {
+        hipLaunchKernelGGL(k_sum_slots<KB>, dim3((unsigned)p->nlong, (C::SLOT_ITEMS * 64 + 255) / 256), dim3(256), 0, st,
+                           p->long_rows, (float*)p->workspace);
         const unsigned grid = (unsigned)((p->nlong + C::WPW - 1) / C::WPW);
         hipLaunchKernelGGL(k_row_long<KB>, dim3(grid), dim3(64 * C::WPW), 0, st, *p);
     }
