@@ -75,6 +75,7 @@ class _TasksDev:
     nlong: int
     nslots: int
     nnz: int
+    ndual: int = 0
 
 
 def _side_to_dev(s, device) -> _SideDev:
@@ -107,7 +108,7 @@ def _to_dev(a, device, dtype) -> torch.Tensor:
 
 def _tasks_to_dev(t: layout.RowTasks, device) -> _TasksDev:
     return _TasksDev(torch.from_numpy(t.tasks).to(device), torch.from_numpy(t.long_rows).to(device),
-                     int(t.tasks.shape[0]), int(t.long_rows.shape[0]), t.nslots, t.nnz)
+                     int(t.tasks.shape[0]), int(t.long_rows.shape[0]), t.nslots, t.nnz, t.ndual)
 
 
 class ALS:

@@ -642,6 +642,147 @@ void k_row_tasks(const als_row_solve_params P) {
     finish_row<KB>(A, P, row, lds_all + wave_u * C::LDS_FLOATS, lane);
 }
 
+// ---------------------------------------------------------------------------
+// Dual form for short rows of wide models (k > 64, at most 64 ratings), solve mode only.
+//
+//   (F^T F + l I) x = F^T r   <=>   x = F^T w,  (F F^T + l I) w = r        (l = lambda + 1e-10)
+//
+// The n x n system (n <= 64) is built on the bf16 matrix cores exactly like the Gram - ratings on both
+// MFMA axes, the k factor columns as the contraction index, same exact 3-way split - and solved by the
+// k = 64 machinery above (blocked Cholesky of a 64 x 64 matrix held in MFMA accumulators; rows past n are
+// identity).  Everything the row needs follows from w in closed form, since F x = F F^T w = r - l w:
+//   bias_new = (n b_old + l sum w) / (n + lambda_b + 1e-10)
+//   d_t      = b_old - bias_new + l w_t                      (residual with the new x and bias)
+// One wave per row, 4 per workgroup, 3 waves per SIMD (the primal k = 128 kernel needs 500 registers and
+// k^3/3 Cholesky flops per row: one wave per SIMD).
+// ---------------------------------------------------------------------------
+template <int KB>
+__global__ __launch_bounds__(256, 3)
+void k_row_dual(const als_row_solve_params P, int64_t task0, int64_t ntail) {
+    using C4 = KCfg<4>;
+    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR, NSLAB = (KP + 31) / 32;
+    __shared__ __attribute__((aligned(16))) float lds_all[4 * C4::LDS_FLOATS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tid = (int64_t)blockIdx.x * 4 + wave;
+    if (tid >= ntail) return;
+    float* Ls = lds_all + wave * C4::LDS_FLOATS;
+    const int row = P.tasks[task0 + tid].row;
+    const int64_t beg = P.indptr[row];
+    const int len = (int)(P.indptr[row + 1] - beg);
+    if (len > 64 || len < 1) {                       // not a task for this kernel: host bug, fail loudly
+        if (lane == 0) atomicMax(P.status, row + 1);
+        return;
+    }
+    const int c = lane & 15, q = lane >> 4;
+    const bool ok = lane < len;
+    const int idx_l = ok ? P.indices[beg + lane] : P.F_zero_row;
+    const float bold = P.bias_self[row];
+    const float mu = (float)*P.mu;
+    const float r_l = ok ? (P.vals[beg + lane] - mu - P.bias_other[idx_l]) - bold : 0.f;
+    const int nblk = (len + 15) >> 4;               // 16-rating blocks in use (wave-uniform)
+    int off[4];
+#pragma unroll
+    for (int I = 0; I < 4; ++I) off[I] = bperm_i(idx_l, 16 * I + c) * P.ld;   // lanes past len: the zero row
+
+    // K = F F^T: rating block I on the M axis, J <= I on the N axis, 32 factor columns per MFMA
+    RowAcc<4> A;
+    A.zero();
+    for (int s = 0; s < NSLAB; ++s) {
+        const bool in = 32 * s + 8 * q < KP;         // a lane's 8 columns are all inside or all outside
+        i32x4 H[4], M[4], L[4];
+#pragma unroll
+        for (int I = 0; I < 4; ++I) {
+            float f[8];
+            if (I < nblk && in) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(P.F + (uint32_t)off[I] + 32 * s + 8 * q);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(P.F + (uint32_t)off[I] + 32 * s + 8 * q + 4);
+                f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w; f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const float x0 = f[e], x1 = f[e + 1];
+                const float h0 = __int_as_float(__float_as_int(x0) & 0xFFFF0000);
+                const float h1 = __int_as_float(__float_as_int(x1) & 0xFFFF0000);
+                const float r0 = x0 - h0, r1 = x1 - h1;                       // exact
+                const float m0 = __int_as_float(__float_as_int(r0) & 0xFFFF0000);
+                const float m1 = __int_as_float(__float_as_int(r1) & 0xFFFF0000);
+                const float l0 = r0 - m0, l1 = r1 - m1;                       // exact, <= 8 significant bits
+                H[I][e >> 1] = pack_hi16(x1, x0);
+                M[I][e >> 1] = pack_hi16(r1, r0);
+                L[I][e >> 1] = pack_hi16(l1, l0);
+            }
+        }
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) {
+                if (bi >= nblk) continue;
+                f32x4 acc = A.acc[blk_idx(bi, bj)];
+                const bf16x8 hi = __builtin_bit_cast(bf16x8, H[bi]), hj = __builtin_bit_cast(bf16x8, H[bj]);
+                const bf16x8 mi = __builtin_bit_cast(bf16x8, M[bi]), mj = __builtin_bit_cast(bf16x8, M[bj]);
+                const bf16x8 li = __builtin_bit_cast(bf16x8, L[bi]), lj = __builtin_bit_cast(bf16x8, L[bj]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(li, hj, acc, 0, 0, 0);     // smallest terms first
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, lj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mi, mj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mi, hj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, mj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, hj, acc, 0, 0, 0);
+                A.acc[blk_idx(bi, bj)] = acc;
+            }
+    }
+    // + l I on the rows in use, identity on the padding rows (their rows / columns of K are zero)
+    const float lam = (P.lambda_row ? P.lambda_row[row] : P.lambda_scalar) + ALS_EPS;
+#pragma unroll
+    for (int J = 0; J < 4; ++J) {
+        const float dv = (16 * J + c < len) ? lam : 1.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A.acc[blk_idx(J, J)][r] += (4 * q + r == c) ? dv : 0.f;
+    }
+    Chol<4> S;
+    S.b[0] = r_l; S.di[0] = 0.f; S.y[0] = 0.f; S.spd = true;
+    chol_panels<4, 0, true>(A, S, Ls, lane);
+    if (!S.spd && lane == 0) atomicMax(P.status, row + 1);
+    float w[1];
+    backward_solve<4>(Ls, S, w, lane);                // w_t in lane t (0 past len: zero right-hand side)
+
+    // x = F^T w: lane (+64 rr) owns factor column lane + 64 rr (storage order); 8 rating rows in flight
+    float x[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) x[rr] = 0.f;
+    for (int i0 = 0; i0 < len; i0 += 8) {
+        float fv[8][NR], wi[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + u, 63);
+            wi[u] = (i0 + u < len) ? readlane_f(w[0], i) : 0.f;
+            const int o = __builtin_amdgcn_readlane(idx_l, i) * P.ld;
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) fv[u][rr] = P.F[(uint32_t)o + min(lane + 64 * rr, KP - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) x[rr] = fmaf(fv[u][rr], wi[u], x[rr]);
+    }
+    const int64_t r64 = row;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr)
+        if (lane + 64 * rr < KP) P.X_out[r64 * P.ld + lane + 64 * rr] = x[rr];
+    const float nnz = (float)len;
+    const float lb = P.lambda_bias_row ? P.lambda_bias_row[row] : P.lambda_bias_scalar;
+    const float sw = wave_sum(ok ? w[0] : 0.f);
+    const float bnew = (nnz * bold + lam * sw) / (nnz + lb + ALS_EPS);
+    if (lane == 0) P.bias_out[row] = bnew;
+    if (P.stat_out) {
+        const float e = ok ? (bold - bnew) + lam * w[0] : 0.f;
+        const float s1 = wave_sum(e), s2 = wave_sum(e * e);
+        if (lane == 0) { P.stat_out[2 * r64] = s1; P.stat_out[2 * r64 + 1] = s2; }
+    }
+}
+
 template <int KB>
 __global__ __launch_bounds__(64 * KCfg<KB>::WPW, KCfg<KB>::MINW)
 void k_row_long(const als_row_solve_params P) {
@@ -679,12 +820,28 @@ void k_sum_slots(const als_long_row* __restrict__ long_rows, float* __restrict__
 template <int KB>
 int launch_row_solve(const als_row_solve_params* p, hipStream_t st) {
     using C = KCfg<KB>;
-    if (p->ntasks > 0) {
-        const unsigned grid = (unsigned)((p->ntasks + C::WPW - 1) / C::WPW);
+    // Short rows at the tail of the (longest-first) task list go to the dual-form kernel when the call is a
+    // plain solve of a wide model (see k_row_dual); `ndual_tail` is the caller's count of such tasks.
+    int64_t ntail = 0;
+    if constexpr (KB >= 5) {
+        if (p->ndual_tail > 0 && p->ndual_tail <= p->ntasks && p->gram_mode == ALS_GRAM_BF16X3 && p->reserved0 == 0 &&
+            p->X_out && p->bias_out && !p->gram_out && !p->factor_out && !p->rhs_out && !p->colsum_out &&
+            !p->sumr_out && !p->sumr2_out && !p->rhs_extra && !p->diag_extra)
+            ntail = p->ndual_tail;
+    }
+    const int64_t nprimal = p->ntasks - ntail;
+    if (nprimal > 0) {
+        als_row_solve_params q = *p;
+        q.ntasks = nprimal;
+        const unsigned grid = (unsigned)((nprimal + C::WPW - 1) / C::WPW);
         if (p->gram_mode == ALS_GRAM_BF16X3)
-            hipLaunchKernelGGL((k_row_tasks<KB, 1>), dim3(grid), dim3(64 * C::WPW), 0, st, *p);
+            hipLaunchKernelGGL((k_row_tasks<KB, 1>), dim3(grid), dim3(64 * C::WPW), 0, st, q);
         else
-            hipLaunchKernelGGL((k_row_tasks<KB, 0>), dim3(grid), dim3(64 * C::WPW), 0, st, *p);
+            hipLaunchKernelGGL((k_row_tasks<KB, 0>), dim3(grid), dim3(64 * C::WPW), 0, st, q);
+    }
+    if constexpr (KB >= 5) {
+        if (ntail > 0)
+            hipLaunchKernelGGL(k_row_dual<KB>, dim3((unsigned)((ntail + 3) / 4)), dim3(256), 0, st, *p, nprimal, ntail);
     }
     if (p->nlong > 0) {
         hipLaunchKernelGGL(k_sum_slots<KB>, dim3((unsigned)p->nlong, (C::SLOT_ITEMS * 64 + 255) / 256), dim3(256), 0, st,

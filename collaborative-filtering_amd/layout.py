@@ -13,6 +13,7 @@ from typing import List, Optional, Tuple
 
 import numpy as np
 
+DUAL_MAX_LEN = 64        # rows this short may be solved in the dual form (csrc/row_solve.hip, k_row_dual)
 SPLIT_CHUNK = 4096          # == ALS_SPLIT_CHUNK in include/als_hip.h
 
 
@@ -81,6 +82,7 @@ class RowTasks:
     long_rows: np.ndarray    # int32 [nlong, 4]   (row, slot0, nslots, 0)
     nslots: int
     nnz: int                 # ratings covered
+    ndual: int = 0           # trailing tasks that are whole rows of at most DUAL_MAX_LEN ratings
 
 
 def build_row_tasks(indptr: np.ndarray, row_begin: int = 0, row_end: Optional[int] = None,
@@ -115,6 +117,10 @@ def build_row_tasks(indptr: np.ndarray, row_begin: int = 0, row_end: Optional[in
     all_slot = np.concatenate([t_slot, -np.ones(s_rows.size, dtype=np.int64)])
     all_len = np.concatenate([t_len, s_len])
     order = np.argsort(-all_len, kind="stable")
+    # whole rows of at most DUAL_MAX_LEN ratings go last (longest-first inside both parts): als_row_solve may
+    # hand that tail to the dual-form kernel (`ndual_tail`, k > 64)
+    short_whole = (all_len[order] <= DUAL_MAX_LEN) & (all_slot[order] < 0)
+    order = np.concatenate([order[~short_whole], order[short_whole]])
     tasks = np.zeros((all_row.size, 4), dtype=np.int32)
     tasks[:, 0] = all_row[order]
     tasks[:, 1] = all_seg[order]
@@ -123,7 +129,7 @@ def build_row_tasks(indptr: np.ndarray, row_begin: int = 0, row_end: Optional[in
     long_rows[:, 0] = l_rows
     long_rows[:, 1] = slot0
     long_rows[:, 2] = l_nseg
-    return RowTasks(tasks, long_rows, nslots, int(cnt.sum()))
+    return RowTasks(tasks, long_rows, nslots, int(cnt.sum()), int(short_whole.sum()))
 
 
 def shard_bounds(nrows: int, world: int, multiple: int = 1) -> Tuple[int, List[Tuple[int, int]]]:

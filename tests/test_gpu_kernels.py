@@ -282,3 +282,75 @@ def test_spd_solve_reports_indefinite_matrices():
     A2 = np.zeros((3, 3))
     be.spd_solve(torch.from_numpy(A2).to(dev), torch.zeros(3, dtype=torch.float64, device=dev), 0.0, status)
     assert int(status.item()) == 1
+
+
+@pytest.mark.parametrize("k", [65, 80, 96, 112, 128, 150, 160])
+def test_dual_form_short_rows_against_numpy_and_the_primal_kernel(k):
+    """Plain solve at k > 64: whole rows of at most 64 ratings (the tail of the task list) are solved in the
+    dual form (n x n system); longer rows and split rows stay primal.  Every row against numpy fp64, the
+    closed-form bias and residual sums against their definitions, and the dual rows against the primal kernel
+    (ndual_tail = 0) on the same input."""
+    torch, layout, side_dev, tasks_dev, be, dev = _env("bf16x3")
+    ncols = 5000
+    lens = [1, 2, 0, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 100, 4097 + 40, 64, 7, 300]
+    nrows = len(lens)
+    side = _random_side(layout, nrows, ncols, lens, seed=3 * k)
+    rng = np.random.default_rng(7 + k)
+    ld = layout.padded_k(k)
+    F = rng.normal(scale=0.3, size=(ncols, k))
+    b_self = rng.normal(scale=0.2, size=nrows).astype(np.float32)
+    b_other = rng.normal(scale=0.2, size=ncols).astype(np.float32)
+    lam_row = rng.uniform(0.5, 4.0, size=nrows).astype(np.float32)
+    mu, lam_b = 3.3, 1.7
+    t = layout.build_row_tasks(side.indptr)
+    n_short = sum(1 for l in lens if 0 < l <= 64)
+    assert t.ndual == n_short and t.nslots == 2
+    sd = side_dev(side, dev)
+    f32 = torch.float32
+    Fd = torch.from_numpy(_pad(F, ld, 1)).to(dev)
+    ws = torch.empty(t.nslots * be.slot_bytes(k) // 4, dtype=f32, device=dev)
+
+    def run(tasks):
+        X = torch.full((nrows, ld), 7.0, dtype=f32, device=dev)
+        bias = torch.from_numpy(b_self.copy()).to(dev)
+        stat = torch.zeros(nrows, 2, dtype=f32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        be.row_solve(k=k, ld=ld, side=sd, F=Fd, zero_row=ncols, bias_self=bias,
+                     bias_other=torch.from_numpy(b_other).to(dev),
+                     mu=torch.tensor([mu], dtype=torch.float64, device=dev), lam=0.0,
+                     lam_row=torch.from_numpy(lam_row).to(dev), lam_b=lam_b, lam_b_row=None,
+                     rhs_extra=None, diag_extra=None, X_out=X, bias_out=bias, gram_out=None, factor_out=None,
+                     rhs_out=None, colsum_out=None, sumr_out=None, status=status, tasks=tasks, workspace=ws,
+                     stat_out=stat)
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0
+        return X.cpu().numpy().astype(np.float64), bias.cpu().numpy().astype(np.float64), stat.cpu().numpy().astype(np.float64)
+
+    td = tasks_dev(t, dev)
+    Xd, bd, sd_ = run(td)
+    td.ndual = 0                                              # same tasks, everything primal
+    Xp, bp, sp = run(td)
+    F32 = F.astype(np.float32).astype(np.float64)
+    for r in range(nrows):
+        lo, hi = side.indptr[r], side.indptr[r + 1]
+        if hi == lo:
+            assert np.all(Xd[r] == 7.0) and bd[r] == b_self[r]
+            continue
+        idx = side.indices[lo:hi]
+        Fr = F32[idx]
+        vals = side.vals[lo:hi].astype(np.float64)
+        rb = vals - mu - b_other[idx]
+        A = Fr.T @ Fr + (lam_row[r] + 1e-10) * np.eye(k)
+        x = np.linalg.solve(A, Fr.T @ (rb - b_self[r]))
+        scale = max(np.max(np.abs(x)), 1e-6)
+        for X, tag in ((Xd, "dual"), (Xp, "primal")):
+            np.testing.assert_allclose(X[r, :k], x, rtol=2e-3, atol=2e-4 * scale, err_msg=f"{tag} row {r} nnz {hi - lo}")
+            assert np.all(X[r, k:] == 0.0)
+        bref = np.sum(rb - Fr @ x) / ((hi - lo) + lam_b + 1e-10)
+        d = rb - Fr @ x - bref
+        for b_, s_, tag in ((bd, sd_, "dual"), (bp, sp, "primal")):
+            assert abs(b_[r] - bref) <= 2e-4 * max(1.0, abs(bref)), (tag, r)
+            assert abs(s_[r, 0] - d.sum()) <= 2e-4 * max(1.0, np.abs(d).sum()), (tag, r, s_[r, 0], d.sum())
+            assert abs(s_[r, 1] - (d * d).sum()) <= 1e-3 * max(1.0, (d * d).sum()), (tag, r, s_[r, 1], (d * d).sum())
+    # the two forms are different roundings of the same solution
+    np.testing.assert_allclose(Xd, Xp, rtol=2e-3, atol=2e-4 * np.abs(Xp).max())

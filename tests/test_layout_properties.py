@@ -32,7 +32,13 @@ def test_row_tasks_cover_every_rating_once(lens, chunk, data):
         segs = sorted((int(s), int(sl)) for r, s, sl, _ in t.tasks if r == row)
         assert [sl for _, sl in segs] == list(range(slot0, slot0 + nslots))
     lens_sorted = [min(chunk, indptr[r + 1] - indptr[r] - s * chunk) for r, s, _, _ in t.tasks]
-    assert lens_sorted == sorted(lens_sorted, reverse=True)              # longest first
+    head, tail = lens_sorted[:len(lens_sorted) - t.ndual], lens_sorted[len(lens_sorted) - t.ndual:]
+    assert head == sorted(head, reverse=True) and tail == sorted(tail, reverse=True)   # longest first, twice
+    # the tail is exactly the whole rows of at most DUAL_MAX_LEN ratings
+    nt = len(t.tasks)
+    for j, (r, s, slot, _) in enumerate(t.tasks):
+        whole_short = slot < 0 and (indptr[r + 1] - indptr[r]) <= layout.DUAL_MAX_LEN
+        assert whole_short == (j >= nt - t.ndual)
     assert t.nnz == int(indptr[e] - indptr[b])
 
 
