@@ -656,23 +656,11 @@ void k_row_tasks(const als_row_solve_params P) {
 // One wave per row, 4 per workgroup, 3 waves per SIMD (the primal k = 128 kernel needs 500 registers and
 // k^3/3 Cholesky flops per row: one wave per SIMD).
 // ---------------------------------------------------------------------------
-template <int KB>
-__global__ __launch_bounds__(256, 3)
-void k_row_dual(const als_row_solve_params P, int64_t task0, int64_t ntail) {
-    using C4 = KCfg<4>;
+// NB = 16-rating blocks of the row (n <= 16 NB): the system is 16 NB x 16 NB and runs on the k = 16 NB machinery
+template <int KB, int NB>
+__device__ __forceinline__ void row_dual(const als_row_solve_params& P, int row, int64_t beg, int len,
+                                         float* __restrict__ Ls, int lane) {
     constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR, NSLAB = (KP + 31) / 32;
-    __shared__ __attribute__((aligned(16))) float lds_all[4 * C4::LDS_FLOATS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t tid = (int64_t)blockIdx.x * 4 + wave;
-    if (tid >= ntail) return;
-    float* Ls = lds_all + wave * C4::LDS_FLOATS;
-    const int row = P.tasks[task0 + tid].row;
-    const int64_t beg = P.indptr[row];
-    const int len = (int)(P.indptr[row + 1] - beg);
-    if (len > 64 || len < 1) {                       // not a task for this kernel: host bug, fail loudly
-        if (lane == 0) atomicMax(P.status, row + 1);
-        return;
-    }
     const int c = lane & 15, q = lane >> 4;
     const bool ok = lane < len;
     const int idx_l = ok ? P.indices[beg + lane] : P.F_zero_row;
@@ -680,18 +668,18 @@ void k_row_dual(const als_row_solve_params P, int64_t task0, int64_t ntail) {
     const float mu = (float)*P.mu;
     const float r_l = ok ? (P.vals[beg + lane] - mu - P.bias_other[idx_l]) - bold : 0.f;
     const int nblk = (len + 15) >> 4;               // 16-rating blocks in use (wave-uniform)
-    int off[4];
+    int off[NB];
 #pragma unroll
-    for (int I = 0; I < 4; ++I) off[I] = bperm_i(idx_l, 16 * I + c) * P.ld;   // lanes past len: the zero row
+    for (int I = 0; I < NB; ++I) off[I] = bperm_i(idx_l, 16 * I + c) * P.ld;   // lanes past len: the zero row
 
     // K = F F^T: rating block I on the M axis, J <= I on the N axis, 32 factor columns per MFMA
-    RowAcc<4> A;
+    RowAcc<NB> A;
     A.zero();
     for (int s = 0; s < NSLAB; ++s) {
         const bool in = 32 * s + 8 * q < KP;         // a lane's 8 columns are all inside or all outside
-        i32x4 H[4], M[4], L[4];
+        i32x4 H[NB], M[NB], L[NB];
 #pragma unroll
-        for (int I = 0; I < 4; ++I) {
+        for (int I = 0; I < NB; ++I) {
             float f[8];
             if (I < nblk && in) {
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(P.F + (uint32_t)off[I] + 32 * s + 8 * q);
@@ -716,7 +704,7 @@ void k_row_dual(const als_row_solve_params P, int64_t task0, int64_t ntail) {
             }
         }
 #pragma unroll
-        for (int bi = 0; bi < 4; ++bi)
+        for (int bi = 0; bi < NB; ++bi)
 #pragma unroll
             for (int bj = 0; bj <= bi; ++bj) {
                 if (bi >= nblk) continue;
@@ -736,17 +724,17 @@ void k_row_dual(const als_row_solve_params P, int64_t task0, int64_t ntail) {
     // + l I on the rows in use, identity on the padding rows (their rows / columns of K are zero)
     const float lam = (P.lambda_row ? P.lambda_row[row] : P.lambda_scalar) + ALS_EPS;
 #pragma unroll
-    for (int J = 0; J < 4; ++J) {
+    for (int J = 0; J < NB; ++J) {
         const float dv = (16 * J + c < len) ? lam : 1.0f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) A.acc[blk_idx(J, J)][r] += (4 * q + r == c) ? dv : 0.f;
     }
-    Chol<4> S;
+    Chol<NB> S;
     S.b[0] = r_l; S.di[0] = 0.f; S.y[0] = 0.f; S.spd = true;
-    chol_panels<4, 0, true>(A, S, Ls, lane);
+    chol_panels<NB, 0, true>(A, S, Ls, lane);
     if (!S.spd && lane == 0) atomicMax(P.status, row + 1);
     float w[1];
-    backward_solve<4>(Ls, S, w, lane);                // w_t in lane t (0 past len: zero right-hand side)
+    backward_solve<NB>(Ls, S, w, lane);                // w_t in lane t (0 past len: zero right-hand side)
 
     // x = F^T w: lane (+64 rr) owns factor column lane + 64 rr (storage order); 8 rating rows in flight
     float x[NR];
@@ -781,6 +769,28 @@ void k_row_dual(const als_row_solve_params P, int64_t task0, int64_t ntail) {
         const float s1 = wave_sum(e), s2 = wave_sum(e * e);
         if (lane == 0) { P.stat_out[2 * r64] = s1; P.stat_out[2 * r64 + 1] = s2; }
     }
+}
+
+template <int KB>
+__global__ __launch_bounds__(256, 3)
+void k_row_dual(const als_row_solve_params P, int64_t task0, int64_t ntail) {
+    using C4 = KCfg<4>;
+    __shared__ __attribute__((aligned(16))) float lds_all[4 * C4::LDS_FLOATS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tid = (int64_t)blockIdx.x * 4 + wave;
+    if (tid >= ntail) return;
+    float* Ls = lds_all + wave * C4::LDS_FLOATS;
+    const int row = P.tasks[task0 + tid].row;
+    const int64_t beg = P.indptr[row];
+    const int len = (int)(P.indptr[row + 1] - beg);
+    if (len > 64 || len < 1) {                       // not a task for this kernel: host bug, fail loudly
+        if (lane == 0) atomicMax(P.status, row + 1);
+        return;
+    }
+    // the tail is sorted by length, so neighbouring waves take the same branch
+    if (len <= 32) row_dual<KB, 2>(P, row, beg, len, Ls, lane);
+    else if (len <= 48) row_dual<KB, 3>(P, row, beg, len, Ls, lane);
+    else row_dual<KB, 4>(P, row, beg, len, Ls, lane);
 }
 
 template <int KB>
