@@ -307,13 +307,15 @@ class _Engine:
         self.csc = _side_to_dev(csc, device)
         uptr_h = self.csr.indptr.cpu().numpy()
         iptr_h = self.csc.indptr.cpu().numpy()
-        self.utasks = _tasks_to_dev(layout.build_row_tasks(uptr_h, self.ub, self.ue), device)
-        self.itasks = _tasks_to_dev(layout.build_row_tasks(iptr_h, self.ib, self.ie), device)
+        dl = layout.dual_max_len(k)          # rows this short are solved in the dual form (k_row_dual)
+        self.utasks = _tasks_to_dev(layout.build_row_tasks(uptr_h, self.ub, self.ue, dual_len=dl), device)
+        self.itasks = _tasks_to_dev(layout.build_row_tasks(iptr_h, self.ib, self.ie, dual_len=dl), device)
         if self.u_chunks > 1:
             sub = self.u_per // self.u_chunks
             lo0 = self.rank * self.u_per
             self.utasks_c = [_tasks_to_dev(layout.build_row_tasks(uptr_h, min(lo0 + c * sub, self.m),
-                                                                  min(lo0 + (c + 1) * sub, self.m)), device)
+                                                                  min(lo0 + (c + 1) * sub, self.m), dual_len=dl),
+                                           device)
                              for c in range(self.u_chunks)]
             self.u_stage = torch.empty(self.u_chunks, self.world, sub, self.ld, dtype=torch.float32, device=device)
             self.bu_stage = torch.empty(self.u_chunks, self.world, sub, dtype=torch.float32, device=device)

@@ -643,7 +643,7 @@ void k_row_tasks(const als_row_solve_params P) {
 }
 
 // ---------------------------------------------------------------------------
-// Dual form for short rows of wide models (k > 64, at most 64 ratings), solve mode only.
+// Dual form for short rows (at most 64 ratings, fewer than k), solve mode only.
 //
 //   (F^T F + l I) x = F^T r   <=>   x = F^T w,  (F F^T + l I) w = r        (l = lambda + 1e-10)
 //
@@ -654,7 +654,9 @@ void k_row_tasks(const als_row_solve_params P) {
 //   bias_new = (n b_old + l sum w) / (n + lambda_b + 1e-10)
 //   d_t      = b_old - bias_new + l w_t                      (residual with the new x and bias)
 // One wave per row, 4 per workgroup, 3 waves per SIMD (the primal k = 128 kernel needs 500 registers and
-// k^3/3 Cholesky flops per row: one wave per SIMD).
+// k^3/3 Cholesky flops per row: one wave per SIMD).  The caller decides which rows qualify (`ndual_tail`):
+// all rows of at most 64 ratings for k > 64; for k <= 64 the rows whose 16-rating blocks are fewer than k/16,
+// i.e. a strictly smaller system (k = 64: n <= 48).
 // ---------------------------------------------------------------------------
 // NB = 16-rating blocks of the row (n <= 16 NB): the system is 16 NB x 16 NB and runs on the k = 16 NB machinery
 template <int KB, int NB>
@@ -788,7 +790,8 @@ void k_row_dual(const als_row_solve_params P, int64_t task0, int64_t ntail) {
         return;
     }
     // the tail is sorted by length, so neighbouring waves take the same branch
-    if (len <= 32) row_dual<KB, 2>(P, row, beg, len, Ls, lane);
+    if (len <= 16) row_dual<KB, 1>(P, row, beg, len, Ls, lane);
+    else if (len <= 32) row_dual<KB, 2>(P, row, beg, len, Ls, lane);
     else if (len <= 48) row_dual<KB, 3>(P, row, beg, len, Ls, lane);
     else row_dual<KB, 4>(P, row, beg, len, Ls, lane);
 }
@@ -833,7 +836,7 @@ int launch_row_solve(const als_row_solve_params* p, hipStream_t st) {
     // Short rows at the tail of the (longest-first) task list go to the dual-form kernel when the call is a
     // plain solve of a wide model (see k_row_dual); `ndual_tail` is the caller's count of such tasks.
     int64_t ntail = 0;
-    if constexpr (KB >= 5) {
+    {
         if (p->ndual_tail > 0 && p->ndual_tail <= p->ntasks && p->gram_mode == ALS_GRAM_BF16X3 && p->reserved0 == 0 &&
             p->X_out && p->bias_out && !p->gram_out && !p->factor_out && !p->rhs_out && !p->colsum_out &&
             !p->sumr_out && !p->sumr2_out && !p->rhs_extra && !p->diag_extra)
@@ -849,7 +852,7 @@ int launch_row_solve(const als_row_solve_params* p, hipStream_t st) {
         else
             hipLaunchKernelGGL((k_row_tasks<KB, 0>), dim3(grid), dim3(64 * C::WPW), 0, st, q);
     }
-    if constexpr (KB >= 5) {
+    {
         if (ntail > 0)
             hipLaunchKernelGGL(k_row_dual<KB>, dim3((unsigned)((ntail + 3) / 4)), dim3(256), 0, st, *p, nprimal, ntail);
     }

@@ -82,11 +82,19 @@ class RowTasks:
     long_rows: np.ndarray    # int32 [nlong, 4]   (row, slot0, nslots, 0)
     nslots: int
     nnz: int                 # ratings covered
-    ndual: int = 0           # trailing tasks that are whole rows of at most DUAL_MAX_LEN ratings
+    ndual: int = 0           # trailing tasks that are whole rows of at most `dual_len` ratings
+
+
+def dual_max_len(k: int) -> int:
+    """Longest row the engine solves in the dual form at rank k: at most 64 ratings for k > 64 (n x n instead
+    of k x k system, 5x fewer cycles per row at k = 128).  For k <= 64 the kernel supports it too (rows with
+    fewer 16-rating blocks than k/16), but at k = 64 it measured the same as the primal kernel (U-step 7.68 ms
+    either way), so the engine leaves those rows primal."""
+    return DUAL_MAX_LEN if padded_k(k) // 16 >= 5 else 0
 
 
 def build_row_tasks(indptr: np.ndarray, row_begin: int = 0, row_end: Optional[int] = None,
-                    chunk: int = SPLIT_CHUNK) -> RowTasks:
+                    chunk: int = SPLIT_CHUNK, dual_len: int = DUAL_MAX_LEN) -> RowTasks:
     """Tasks for rows [row_begin, row_end) with at least one rating.
 
     Rows longer than `chunk` are split into segments whose partial normal
@@ -117,9 +125,9 @@ def build_row_tasks(indptr: np.ndarray, row_begin: int = 0, row_end: Optional[in
     all_slot = np.concatenate([t_slot, -np.ones(s_rows.size, dtype=np.int64)])
     all_len = np.concatenate([t_len, s_len])
     order = np.argsort(-all_len, kind="stable")
-    # whole rows of at most DUAL_MAX_LEN ratings go last (longest-first inside both parts): als_row_solve may
+    # whole rows of at most `dual_len` ratings go last (longest-first inside both parts): als_row_solve may
     # hand that tail to the dual-form kernel (`ndual_tail`, k > 64)
-    short_whole = (all_len[order] <= DUAL_MAX_LEN) & (all_slot[order] < 0)
+    short_whole = (all_len[order] <= dual_len) & (all_slot[order] < 0)
     order = np.concatenate([order[~short_whole], order[short_whole]])
     tasks = np.zeros((all_row.size, 4), dtype=np.int32)
     tasks[:, 0] = all_row[order]

@@ -119,10 +119,12 @@ typedef struct als_row_solve_params {
                                    ALS_GRAM_BF16X3: exact 3-way bf16 split of every float, six cross
                                    products on v_mfma_f32_16x16x32_bf16, fp32 accumulate (same accuracy
                                    class, the matrix cores run beside the VALU) */
-    int32_t ndual_tail;         /* number of TRAILING tasks that are whole rows (slot < 0) of at most 64 ratings;
-                                   honoured for k > 64 in plain solve calls (no by-product outputs, no
-                                   rhs_extra / diag_extra, bf16x3 Gram): those rows are solved in the dual
-                                   form (n x n instead of k x k system, same solution); 0 = never */
+    int32_t ndual_tail;         /* number of TRAILING tasks that are whole rows (slot < 0) of at most 64 ratings
+                                   to be solved in the dual form (n x n instead of k x k system, same
+                                   solution); honoured in plain solve calls (no by-product outputs, no
+                                   rhs_extra / diag_extra, bf16x3 Gram).  Pays when the n x n system is much
+                                   the smaller one (k > 64: 5x per row at k = 128; at k = 64, n <= 48 it measured
+                                   equal to the primal kernel); 0 = never */
     const int64_t* indptr;
     const int32_t* indices;
     const float*   vals;

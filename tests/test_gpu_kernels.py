@@ -284,7 +284,7 @@ def test_spd_solve_reports_indefinite_matrices():
     assert int(status.item()) == 1
 
 
-@pytest.mark.parametrize("k", [65, 80, 96, 112, 128, 150, 160])
+@pytest.mark.parametrize("k", [20, 32, 48, 50, 64, 65, 80, 96, 112, 128, 150, 160])
 def test_dual_form_short_rows_against_numpy_and_the_primal_kernel(k):
     """Plain solve at k > 64: whole rows of at most 64 ratings (the tail of the task list) are solved in the
     dual form (n x n system); longer rows and split rows stay primal.  Every row against numpy fp64, the
@@ -302,8 +302,12 @@ def test_dual_form_short_rows_against_numpy_and_the_primal_kernel(k):
     b_other = rng.normal(scale=0.2, size=ncols).astype(np.float32)
     lam_row = rng.uniform(0.5, 4.0, size=nrows).astype(np.float32)
     mu, lam_b = 3.3, 1.7
-    t = layout.build_row_tasks(side.indptr)
-    n_short = sum(1 for l in lens if 0 < l <= 64)
+    # the engine uses the dual form above k = 64 (layout.dual_max_len); the kernel also takes rows whose
+    # 16-rating blocks are fewer than k/16 at smaller k - exercised here as well
+    dl = 64 if k > 64 else 16 * (layout.padded_k(k) // 16 - 1)
+    assert layout.dual_max_len(k) == (64 if k > 64 else 0)
+    t = layout.build_row_tasks(side.indptr, dual_len=dl)
+    n_short = sum(1 for l in lens if 0 < l <= dl)
     assert t.ndual == n_short and t.nslots == 2
     sd = side_dev(side, dev)
     f32 = torch.float32
