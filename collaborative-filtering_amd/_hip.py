@@ -26,7 +26,7 @@ class RowSolveParams(C.Structure):
     """struct als_row_solve_params (include/als_hip.h)."""
     _fields_ = [
         ("k", _i32), ("ld", _i32), ("nrows", _i64), ("F_zero_row", _i32), ("reserved0", _i32),
-        ("gram_mode", _i32), ("ndual_tail", _i32),
+        ("gram_mode", _i32), ("ndual_tail", _i32), ("ndual_mid", _i32), ("reserved1", _i32),
         ("indptr", _vp), ("indices", _vp), ("vals", _vp), ("F", _vp),
         ("bias_self", _vp), ("bias_other", _vp), ("mu", _vp),
         ("lambda_scalar", _f32), ("lambda_row", _vp),

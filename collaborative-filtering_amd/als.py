@@ -76,6 +76,7 @@ class _TasksDev:
     nslots: int
     nnz: int
     ndual: int = 0
+    nmid: int = 0
 
 
 def _side_to_dev(s, device) -> _SideDev:
@@ -108,7 +109,7 @@ def _to_dev(a, device, dtype) -> torch.Tensor:
 
 def _tasks_to_dev(t: layout.RowTasks, device) -> _TasksDev:
     return _TasksDev(torch.from_numpy(t.tasks).to(device), torch.from_numpy(t.long_rows).to(device),
-                     int(t.tasks.shape[0]), int(t.long_rows.shape[0]), t.nslots, t.nnz, t.ndual)
+                     int(t.tasks.shape[0]), int(t.long_rows.shape[0]), t.nslots, t.nnz, t.ndual, t.nmid)
 
 
 class ALS:
@@ -308,13 +309,14 @@ class _Engine:
         uptr_h = self.csr.indptr.cpu().numpy()
         iptr_h = self.csc.indptr.cpu().numpy()
         dl = layout.dual_max_len(k)          # rows this short are solved in the dual form (k_row_dual)
-        self.utasks = _tasks_to_dev(layout.build_row_tasks(uptr_h, self.ub, self.ue, dual_len=dl), device)
-        self.itasks = _tasks_to_dev(layout.build_row_tasks(iptr_h, self.ib, self.ie, dual_len=dl), device)
+        dm = layout.dual_mid_len(k)          # ... and rows up to this length above k = 96 (k_row_dual_mid)
+        self.utasks = _tasks_to_dev(layout.build_row_tasks(uptr_h, self.ub, self.ue, dual_len=dl, mid_len=dm), device)
+        self.itasks = _tasks_to_dev(layout.build_row_tasks(iptr_h, self.ib, self.ie, dual_len=dl, mid_len=dm), device)
         if self.u_chunks > 1:
             sub = self.u_per // self.u_chunks
             lo0 = self.rank * self.u_per
             self.utasks_c = [_tasks_to_dev(layout.build_row_tasks(uptr_h, min(lo0 + c * sub, self.m),
-                                                                  min(lo0 + (c + 1) * sub, self.m), dual_len=dl),
+                                                                  min(lo0 + (c + 1) * sub, self.m), dual_len=dl, mid_len=dm),
                                            device)
                              for c in range(self.u_chunks)]
             self.u_stage = torch.empty(self.u_chunks, self.world, sub, self.ld, dtype=torch.float32, device=device)

@@ -70,7 +70,8 @@ class HipBackend:
         p.rhs_out, p.colsum_out, p.sumr_out, p.status = _p(rhs_out), _p(colsum_out), _p(sumr_out), _p(status)
         p.sumr2_out, p.stat_out = _p(sumr2_out), _p(stat_out)
         p.tasks, p.ntasks = _p(tasks.tasks), tasks.ntasks
-        p.ndual_tail = int(getattr(tasks, "ndual", 0))      # honoured by the library for plain solves at k > 64
+        p.ndual_tail = int(getattr(tasks, "ndual", 0))      # honoured by the library for plain solves
+        p.ndual_mid = int(getattr(tasks, "nmid", 0))
         p.long_rows, p.nlong = _p(tasks.long_rows), tasks.nlong
         p.workspace = _p(workspace)
         self._check(self.lib.als_row_solve(C.byref(p), self._stream()), "als_row_solve")

@@ -658,21 +658,31 @@ void k_row_tasks(const als_row_solve_params P) {
 // all rows of at most 64 ratings for k > 64; for k <= 64 the rows whose 16-rating blocks are fewer than k/16,
 // i.e. a strictly smaller system (k = 64: n <= 48).
 // ---------------------------------------------------------------------------
-// NB = 16-rating blocks of the row (n <= 16 NB): the system is 16 NB x 16 NB and runs on the k = 16 NB machinery
+// NB = 16-rating blocks of the row (n <= 16 NB): the system is 16 NB x 16 NB and runs on the k = 16 NB
+// machinery; rating t of the row lives in lane t & 63, slot t >> 6 (two slots for NB > 4).
 template <int KB, int NB>
 __device__ __forceinline__ void row_dual(const als_row_solve_params& P, int row, int64_t beg, int len,
                                          float* __restrict__ Ls, int lane) {
     constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR, NSLAB = (KP + 31) / 32;
+    constexpr int NS = KCfg<NB>::NR;                 // rating slots per lane
     const int c = lane & 15, q = lane >> 4;
-    const bool ok = lane < len;
-    const int idx_l = ok ? P.indices[beg + lane] : P.F_zero_row;
     const float bold = P.bias_self[row];
     const float mu = (float)*P.mu;
-    const float r_l = ok ? (P.vals[beg + lane] - mu - P.bias_other[idx_l]) - bold : 0.f;
+    bool ok[NS];
+    int idx_l[NS];
+    float r_l[NS];
+#pragma unroll
+    for (int ss = 0; ss < NS; ++ss) {
+        const int t = lane + 64 * ss;
+        ok[ss] = t < len;
+        idx_l[ss] = ok[ss] ? P.indices[beg + t] : P.F_zero_row;
+        r_l[ss] = ok[ss] ? (P.vals[beg + t] - mu - P.bias_other[idx_l[ss]]) - bold : 0.f;
+    }
     const int nblk = (len + 15) >> 4;               // 16-rating blocks in use (wave-uniform)
     int off[NB];
 #pragma unroll
-    for (int I = 0; I < NB; ++I) off[I] = bperm_i(idx_l, 16 * I + c) * P.ld;   // lanes past len: the zero row
+    for (int I = 0; I < NB; ++I)                     // lanes past len: the zero row
+        off[I] = bperm_i(idx_l[(16 * I) >> 6], (16 * I + c) & 63) * P.ld;
 
     // K = F F^T: rating block I on the M axis, J <= I on the N axis, 32 factor columns per MFMA
     RowAcc<NB> A;
@@ -732,30 +742,36 @@ __device__ __forceinline__ void row_dual(const als_row_solve_params& P, int row,
         for (int r = 0; r < 4; ++r) A.acc[blk_idx(J, J)][r] += (4 * q + r == c) ? dv : 0.f;
     }
     Chol<NB> S;
-    S.b[0] = r_l; S.di[0] = 0.f; S.y[0] = 0.f; S.spd = true;
+#pragma unroll
+    for (int ss = 0; ss < NS; ++ss) { S.b[ss] = r_l[ss]; S.di[ss] = 0.f; S.y[ss] = 0.f; }
+    S.spd = true;
     chol_panels<NB, 0, true>(A, S, Ls, lane);
     if (!S.spd && lane == 0) atomicMax(P.status, row + 1);
-    float w[1];
-    backward_solve<NB>(Ls, S, w, lane);                // w_t in lane t (0 past len: zero right-hand side)
+    float w[NS];
+    backward_solve<NB>(Ls, S, w, lane);               // w_t in lane t & 63, slot t >> 6 (0 past len)
 
     // x = F^T w: lane (+64 rr) owns factor column lane + 64 rr (storage order); 8 rating rows in flight
     float x[NR];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) x[rr] = 0.f;
-    for (int i0 = 0; i0 < len; i0 += 8) {
-        float fv[8][NR], wi[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = min(i0 + u, 63);
-            wi[u] = (i0 + u < len) ? readlane_f(w[0], i) : 0.f;
-            const int o = __builtin_amdgcn_readlane(idx_l, i) * P.ld;
+    for (int ss = 0; ss < NS; ++ss) {
+        const int lim = min(len - 64 * ss, 64);
+        for (int i0 = 0; i0 < lim; i0 += 8) {
+            float fv[8][NR], wi[8];
 #pragma unroll
-            for (int rr = 0; rr < NR; ++rr) fv[u][rr] = P.F[(uint32_t)o + min(lane + 64 * rr, KP - 1)];
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u, 63);
+                wi[u] = (i0 + u < lim) ? readlane_f(w[ss], i) : 0.f;
+                const int o = __builtin_amdgcn_readlane(idx_l[ss], i) * P.ld;
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) fv[u][rr] = P.F[(uint32_t)o + min(lane + 64 * rr, KP - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) x[rr] = fmaf(fv[u][rr], wi[u], x[rr]);
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int rr = 0; rr < NR; ++rr) x[rr] = fmaf(fv[u][rr], wi[u], x[rr]);
     }
     const int64_t r64 = row;
 #pragma unroll
@@ -763,12 +779,21 @@ __device__ __forceinline__ void row_dual(const als_row_solve_params& P, int row,
         if (lane + 64 * rr < KP) P.X_out[r64 * P.ld + lane + 64 * rr] = x[rr];
     const float nnz = (float)len;
     const float lb = P.lambda_bias_row ? P.lambda_bias_row[row] : P.lambda_bias_scalar;
-    const float sw = wave_sum(ok ? w[0] : 0.f);
+    float wsum = 0.f;
+#pragma unroll
+    for (int ss = 0; ss < NS; ++ss) wsum += ok[ss] ? w[ss] : 0.f;
+    const float sw = wave_sum(wsum);
     const float bnew = (nnz * bold + lam * sw) / (nnz + lb + ALS_EPS);
     if (lane == 0) P.bias_out[row] = bnew;
     if (P.stat_out) {
-        const float e = ok ? (bold - bnew) + lam * w[0] : 0.f;
-        const float s1 = wave_sum(e), s2 = wave_sum(e * e);
+        float e1 = 0.f, e2 = 0.f;
+#pragma unroll
+        for (int ss = 0; ss < NS; ++ss) {
+            const float e = ok[ss] ? (bold - bnew) + lam * w[ss] : 0.f;
+            e1 += e;
+            e2 = fmaf(e, e, e2);
+        }
+        const float s1 = wave_sum(e1), s2 = wave_sum(e2);
         if (lane == 0) { P.stat_out[2 * r64] = s1; P.stat_out[2 * r64 + 1] = s2; }
     }
 }
@@ -794,6 +819,28 @@ void k_row_dual(const als_row_solve_params P, int64_t task0, int64_t ntail) {
     else if (len <= 32) row_dual<KB, 2>(P, row, beg, len, Ls, lane);
     else if (len <= 48) row_dual<KB, 3>(P, row, beg, len, Ls, lane);
     else row_dual<KB, 4>(P, row, beg, len, Ls, lane);
+}
+
+// rows of 65 ... 96 ratings of models with k > 96: an 80- or 96-size system on the k = 80 / 96 machinery
+// (two matrix rows per lane, two waves per workgroup and per SIMD)
+template <int KB>
+__global__ __launch_bounds__(128, 2)
+void k_row_dual_mid(const als_row_solve_params P, int64_t task0, int64_t nmid) {
+    using C6 = KCfg<6>;
+    __shared__ __attribute__((aligned(16))) float lds_all[2 * C6::LDS_FLOATS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tid = (int64_t)blockIdx.x * 2 + wave;
+    if (tid >= nmid) return;
+    float* Ls = lds_all + wave * C6::LDS_FLOATS;
+    const int row = P.tasks[task0 + tid].row;
+    const int64_t beg = P.indptr[row];
+    const int len = (int)(P.indptr[row + 1] - beg);
+    if (len > 96 || len <= 64) {                     // not a task for this kernel: host bug, fail loudly
+        if (lane == 0) atomicMax(P.status, row + 1);
+        return;
+    }
+    if (len <= 80) row_dual<KB, 5>(P, row, beg, len, Ls, lane);
+    else row_dual<KB, 6>(P, row, beg, len, Ls, lane);
 }
 
 template <int KB>
@@ -833,16 +880,19 @@ void k_sum_slots(const als_long_row* __restrict__ long_rows, float* __restrict__
 template <int KB>
 int launch_row_solve(const als_row_solve_params* p, hipStream_t st) {
     using C = KCfg<KB>;
-    // Short rows at the tail of the (longest-first) task list go to the dual-form kernel when the call is a
-    // plain solve of a wide model (see k_row_dual); `ndual_tail` is the caller's count of such tasks.
-    int64_t ntail = 0;
-    {
-        if (p->ndual_tail > 0 && p->ndual_tail <= p->ntasks && p->gram_mode == ALS_GRAM_BF16X3 && p->reserved0 == 0 &&
-            p->X_out && p->bias_out && !p->gram_out && !p->factor_out && !p->rhs_out && !p->colsum_out &&
-            !p->sumr_out && !p->sumr2_out && !p->rhs_extra && !p->diag_extra)
-            ntail = p->ndual_tail;
+    // Short rows at the tail of the task list go to the dual-form kernels when the call is a plain solve
+    // (see k_row_dual): `ndual_tail` whole rows of at most 64 ratings, preceded - k > 96 only, where it is the
+    // smaller system - by `ndual_mid` whole rows of 65 ... 96 ratings.  Any by-product output, extra
+    // right-hand side or diagonal, the f32 Gram mode or an ablation flag keeps every row primal.
+    const bool plain = p->gram_mode == ALS_GRAM_BF16X3 && p->reserved0 == 0 && p->X_out && p->bias_out &&
+                       !p->gram_out && !p->factor_out && !p->rhs_out && !p->colsum_out && !p->sumr_out &&
+                       !p->sumr2_out && !p->rhs_extra && !p->diag_extra;
+    int64_t ntail = 0, nmid = 0;
+    if (plain && p->ndual_tail >= 0 && p->ndual_mid >= 0 && (int64_t)p->ndual_tail + p->ndual_mid <= p->ntasks) {
+        ntail = p->ndual_tail;
+        if constexpr (KB >= 7) nmid = p->ndual_mid;        // (k <= 96: those rows stay with the primal tasks)
     }
-    const int64_t nprimal = p->ntasks - ntail;
+    const int64_t nprimal = p->ntasks - ntail - nmid;
     if (nprimal > 0) {
         als_row_solve_params q = *p;
         q.ntasks = nprimal;
@@ -854,7 +904,11 @@ int launch_row_solve(const als_row_solve_params* p, hipStream_t st) {
     }
     {
         if (ntail > 0)
-            hipLaunchKernelGGL(k_row_dual<KB>, dim3((unsigned)((ntail + 3) / 4)), dim3(256), 0, st, *p, nprimal, ntail);
+            hipLaunchKernelGGL(k_row_dual<KB>, dim3((unsigned)((ntail + 3) / 4)), dim3(256), 0, st, *p, nprimal + nmid, ntail);
+    }
+    if constexpr (KB >= 7) {
+        if (nmid > 0)
+            hipLaunchKernelGGL(k_row_dual_mid<KB>, dim3((unsigned)((nmid + 1) / 2)), dim3(128), 0, st, *p, nprimal, nmid);
     }
     if (p->nlong > 0) {
         hipLaunchKernelGGL(k_sum_slots<KB>, dim3((unsigned)p->nlong, (C::SLOT_ITEMS * 64 + 255) / 256), dim3(256), 0, st,

@@ -14,6 +14,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 
 DUAL_MAX_LEN = 64        # rows this short may be solved in the dual form (csrc/row_solve.hip, k_row_dual)
+DUAL_MID_LEN = 96        # ... and, above k = 96, rows up to this length (k_row_dual_mid)
 SPLIT_CHUNK = 4096          # == ALS_SPLIT_CHUNK in include/als_hip.h
 
 
@@ -83,6 +84,7 @@ class RowTasks:
     nslots: int
     nnz: int                 # ratings covered
     ndual: int = 0           # trailing tasks that are whole rows of at most `dual_len` ratings
+    nmid: int = 0            # tasks just before them: whole rows of dual_len < n <= `mid_len` ratings
 
 
 def dual_max_len(k: int) -> int:
@@ -93,8 +95,14 @@ def dual_max_len(k: int) -> int:
     return DUAL_MAX_LEN if padded_k(k) // 16 >= 5 else 0
 
 
+def dual_mid_len(k: int) -> int:
+    """Above k = 96 rows of 65 ... 96 ratings take the dual form too (an 80- or 96-size system at two waves
+    per SIMD instead of the k x k one at one wave per SIMD); 0 = no such class."""
+    return DUAL_MID_LEN if padded_k(k) // 16 >= 7 else 0
+
+
 def build_row_tasks(indptr: np.ndarray, row_begin: int = 0, row_end: Optional[int] = None,
-                    chunk: int = SPLIT_CHUNK, dual_len: int = DUAL_MAX_LEN) -> RowTasks:
+                    chunk: int = SPLIT_CHUNK, dual_len: int = DUAL_MAX_LEN, mid_len: int = 0) -> RowTasks:
     """Tasks for rows [row_begin, row_end) with at least one rating.
 
     Rows longer than `chunk` are split into segments whose partial normal
@@ -127,8 +135,11 @@ def build_row_tasks(indptr: np.ndarray, row_begin: int = 0, row_end: Optional[in
     order = np.argsort(-all_len, kind="stable")
     # whole rows of at most `dual_len` ratings go last (longest-first inside both parts): als_row_solve may
     # hand that tail to the dual-form kernel (`ndual_tail`, k > 64)
-    short_whole = (all_len[order] <= dual_len) & (all_slot[order] < 0)
-    order = np.concatenate([order[~short_whole], order[short_whole]])
+    # ... preceded by the whole rows of dual_len < n <= mid_len ratings (`ndual_mid`, k > 96)
+    whole = all_slot[order] < 0
+    short_whole = (all_len[order] <= dual_len) & whole
+    mid_whole = (all_len[order] <= mid_len) & whole & ~short_whole
+    order = np.concatenate([order[~short_whole & ~mid_whole], order[mid_whole], order[short_whole]])
     tasks = np.zeros((all_row.size, 4), dtype=np.int32)
     tasks[:, 0] = all_row[order]
     tasks[:, 1] = all_seg[order]
@@ -137,7 +148,7 @@ def build_row_tasks(indptr: np.ndarray, row_begin: int = 0, row_end: Optional[in
     long_rows[:, 0] = l_rows
     long_rows[:, 1] = slot0
     long_rows[:, 2] = l_nseg
-    return RowTasks(tasks, long_rows, nslots, int(cnt.sum()), int(short_whole.sum()))
+    return RowTasks(tasks, long_rows, nslots, int(cnt.sum()), int(short_whole.sum()), int(mid_whole.sum()))
 
 
 def shard_bounds(nrows: int, world: int, multiple: int = 1) -> Tuple[int, List[Tuple[int, int]]]:

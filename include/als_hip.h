@@ -125,6 +125,9 @@ typedef struct als_row_solve_params {
                                    rhs_extra / diag_extra, bf16x3 Gram).  Pays when the n x n system is much
                                    the smaller one (k > 64: 5x per row at k = 128; at k = 64, n <= 48 it measured
                                    equal to the primal kernel); 0 = never */
+    int32_t ndual_mid;          /* number of tasks just BEFORE that tail that are whole rows of 65 ... 96 ratings,
+                                   for the dual form at k > 96 (an 80- or 96-size system); 0 = never */
+    int32_t reserved1;
     const int64_t* indptr;
     const int32_t* indices;
     const float*   vals;

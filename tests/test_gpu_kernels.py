@@ -292,7 +292,8 @@ def test_dual_form_short_rows_against_numpy_and_the_primal_kernel(k):
     (ndual_tail = 0) on the same input."""
     torch, layout, side_dev, tasks_dev, be, dev = _env("bf16x3")
     ncols = 5000
-    lens = [1, 2, 0, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 100, 4097 + 40, 64, 7, 300]
+    lens = [1, 2, 0, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 100, 4097 + 40, 64, 7, 300, 66, 79, 80, 81, 95,
+            96, 97]
     nrows = len(lens)
     side = _random_side(layout, nrows, ncols, lens, seed=3 * k)
     rng = np.random.default_rng(7 + k)
@@ -306,9 +307,10 @@ def test_dual_form_short_rows_against_numpy_and_the_primal_kernel(k):
     # 16-rating blocks are fewer than k/16 at smaller k - exercised here as well
     dl = 64 if k > 64 else 16 * (layout.padded_k(k) // 16 - 1)
     assert layout.dual_max_len(k) == (64 if k > 64 else 0)
-    t = layout.build_row_tasks(side.indptr, dual_len=dl)
+    dm = layout.dual_mid_len(k)                               # 96 above k = 96: rows of 65 ... 96 ratings
+    t = layout.build_row_tasks(side.indptr, dual_len=dl, mid_len=dm)
     n_short = sum(1 for l in lens if 0 < l <= dl)
-    assert t.ndual == n_short and t.nslots == 2
+    assert t.ndual == n_short and t.nslots == 2 and t.nmid == sum(1 for l in lens if dl < l <= dm)
     sd = side_dev(side, dev)
     f32 = torch.float32
     Fd = torch.from_numpy(_pad(F, ld, 1)).to(dev)
@@ -332,7 +334,7 @@ def test_dual_form_short_rows_against_numpy_and_the_primal_kernel(k):
 
     td = tasks_dev(t, dev)
     Xd, bd, sd_ = run(td)
-    td.ndual = 0                                              # same tasks, everything primal
+    td.ndual = td.nmid = 0                                    # same tasks, everything primal
     Xp, bp, sp = run(td)
     F32 = F.astype(np.float32).astype(np.float64)
     for r in range(nrows):
@@ -358,3 +360,35 @@ def test_dual_form_short_rows_against_numpy_and_the_primal_kernel(k):
             assert abs(s_[r, 1] - (d * d).sum()) <= 1e-3 * max(1.0, (d * d).sum()), (tag, r, s_[r, 1], (d * d).sum())
     # the two forms are different roundings of the same solution
     np.testing.assert_allclose(Xd, Xp, rtol=2e-3, atol=2e-4 * np.abs(Xp).max())
+
+
+def test_dual_classes_are_ignored_by_calls_with_byproducts():
+    """Regression: a factor-only call (no X_out) whose task list carries dual classes (here: only the
+    65...96 class, no short rows) must keep every row primal - the dual kernels write X_out."""
+    torch, layout, side_dev, tasks_dev, be, dev = _env("bf16x3")
+    k, ncols = 128, 3000
+    lens = [70, 80, 96, 200, 90]
+    nrows = len(lens)
+    side = _random_side(layout, nrows, ncols, lens, seed=5)
+    rng = np.random.default_rng(6)
+    ld = layout.padded_k(k)
+    t = layout.build_row_tasks(side.indptr, dual_len=64, mid_len=96)
+    assert t.ndual == 0 and t.nmid == 4
+    f32 = torch.float32
+    F = torch.from_numpy(_pad(rng.normal(scale=0.3, size=(ncols, k)), ld, 1)).to(dev)
+    factor = torch.zeros(nrows * ld * ld, dtype=f32, device=dev)
+    rhs = torch.zeros(nrows, ld, dtype=f32, device=dev)
+    cs = torch.zeros(nrows, ld, dtype=f32, device=dev)
+    sumr = torch.zeros(nrows, dtype=f32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    be.row_solve(k=k, ld=ld, side=side_dev(side, dev), F=F, zero_row=ncols,
+                 bias_self=torch.zeros(nrows, dtype=f32, device=dev), bias_other=torch.zeros(ncols, dtype=f32, device=dev),
+                 mu=torch.tensor([3.0], dtype=torch.float64, device=dev), lam=2.0, lam_row=None, lam_b=1.0,
+                 lam_b_row=None, rhs_extra=None, diag_extra=None, X_out=None, bias_out=None, gram_out=None,
+                 factor_out=factor, rhs_out=rhs, colsum_out=cs, sumr_out=sumr, status=status,
+                 tasks=tasks_dev(t, dev), workspace=None)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    M = factor.view(nrows, ld, ld).cpu().numpy()
+    assert all(np.all(np.diag(M[r]) > 0) for r in range(nrows))         # every row was factorised (1/L_ii > 0)
+    assert np.all(np.abs(rhs.cpu().numpy()).sum(axis=1) > 0)

@@ -32,6 +32,7 @@ def test_row_tasks_cover_every_rating_once(lens, chunk, data):
         segs = sorted((int(s), int(sl)) for r, s, sl, _ in t.tasks if r == row)
         assert [sl for _, sl in segs] == list(range(slot0, slot0 + nslots))
     lens_sorted = [min(chunk, indptr[r + 1] - indptr[r] - s * chunk) for r, s, _, _ in t.tasks]
+    assert t.nmid == 0                                                    # mid_len defaults to 0
     head, tail = lens_sorted[:len(lens_sorted) - t.ndual], lens_sorted[len(lens_sorted) - t.ndual:]
     assert head == sorted(head, reverse=True) and tail == sorted(tail, reverse=True)   # longest first, twice
     # the tail is exactly the whole rows of at most DUAL_MAX_LEN ratings
@@ -121,3 +122,20 @@ def test_coo_to_sides_round_trip(m, n, seed):
         rows = csc.indices[csc.indptr[i]:csc.indptr[i + 1]]
         assert np.all(np.diff(rows) > 0)
         np.testing.assert_array_equal(dense[rows, i], csc.vals[csc.indptr[i]:csc.indptr[i + 1]])
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.lists(st.integers(0, 200), min_size=1, max_size=80))
+def test_row_tasks_three_classes(lens):
+    """dual_len / mid_len split the whole rows into [others | 65..96 | <= 64], longest first inside each."""
+    indptr = np.zeros(len(lens) + 1, dtype=np.int64)
+    indptr[1:] = np.cumsum(lens)
+    t = layout.build_row_tasks(indptr, dual_len=64, mid_len=96)
+    n = len(t.tasks)
+    ln = [int(indptr[r + 1] - indptr[r]) for r, _, _, _ in t.tasks]
+    assert t.ndual == sum(1 for l in lens if 0 < l <= 64) and t.nmid == sum(1 for l in lens if 64 < l <= 96)
+    a, b = n - t.ndual - t.nmid, n - t.ndual
+    assert all(l > 96 for l in ln[:a]) and all(64 < l <= 96 for l in ln[a:b]) and all(0 < l <= 64 for l in ln[b:])
+    for part in (ln[:a], ln[a:b], ln[b:]):
+        assert part == sorted(part, reverse=True)
+
