@@ -392,3 +392,47 @@ def test_dual_classes_are_ignored_by_calls_with_byproducts():
     M = factor.view(nrows, ld, ld).cpu().numpy()
     assert all(np.all(np.diag(M[r]) > 0) for r in range(nrows))         # every row was factorised (1/L_ii > 0)
     assert np.all(np.abs(rhs.cpu().numpy()).sum(axis=1) > 0)
+
+
+def test_dual_and_primal_agree_on_random_shapes():
+    """Seeded sweep over ranks and row-length mixes: the dual classes (<= 64 ratings; 65...96 above k = 96)
+    and the primal kernel must agree row by row within the fp32 tolerance, including bias and residual sums."""
+    torch, layout, side_dev, tasks_dev, be, dev = _env("bf16x3")
+    rng = np.random.default_rng(2024)
+    f32 = torch.float32
+    for trial in range(12):
+        k = int(rng.integers(65, 161))
+        ncols = int(rng.integers(200, 3000))
+        nrows = int(rng.integers(5, 60))
+        lens = [int(x) for x in np.minimum(rng.integers(0, 130, size=nrows), ncols)]
+        side = _random_side(layout, nrows, ncols, lens, seed=1000 + trial)
+        ld = layout.padded_k(k)
+        t = layout.build_row_tasks(side.indptr, dual_len=64, mid_len=layout.dual_mid_len(k))
+        Fd = torch.from_numpy(_pad(rng.normal(scale=0.3, size=(ncols, k)), ld, 1)).to(dev)
+        b_self = torch.from_numpy(rng.normal(scale=0.2, size=nrows).astype(np.float32)).to(dev)
+        b_other = torch.from_numpy(rng.normal(scale=0.2, size=ncols).astype(np.float32)).to(dev)
+        lam = float(rng.uniform(0.05, 5.0))
+        sd = side_dev(side, dev)
+
+        def run(tasks):
+            X = torch.zeros(nrows, ld, dtype=f32, device=dev)
+            bias = b_self.clone()
+            stat = torch.zeros(nrows, 2, dtype=f32, device=dev)
+            status = torch.zeros(1, dtype=torch.int32, device=dev)
+            be.row_solve(k=k, ld=ld, side=sd, F=Fd, zero_row=ncols, bias_self=bias, bias_other=b_other,
+                         mu=torch.tensor([3.1], dtype=torch.float64, device=dev), lam=lam, lam_row=None, lam_b=1.3,
+                         lam_b_row=None, rhs_extra=None, diag_extra=None, X_out=X, bias_out=bias, gram_out=None,
+                         factor_out=None, rhs_out=None, colsum_out=None, sumr_out=None, status=status, tasks=tasks,
+                         workspace=None, stat_out=stat)
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0
+            return X.cpu().numpy(), bias.cpu().numpy(), stat.cpu().numpy()
+
+        td = tasks_dev(t, dev)
+        Xd, bd, sdl = run(td)
+        td.ndual = td.nmid = 0
+        Xp, bp, sp = run(td)
+        scale = max(float(np.abs(Xp).max()), 1e-6)
+        np.testing.assert_allclose(Xd, Xp, rtol=0, atol=5e-4 * scale, err_msg=f"trial {trial} k {k}")
+        np.testing.assert_allclose(bd, bp, rtol=0, atol=3e-4)
+        np.testing.assert_allclose(sdl, sp, rtol=2e-3, atol=2e-3)
