@@ -43,6 +43,7 @@ SIZES = {   # name: (m, n, nnz, k)   - cfg4 is the headline; the others are diag
     "cfg4": (1_000_000, 100_000, 100_000_000, 64),
     "cfg4-small": (100_000, 10_000, 5_000_000, 64),       # rehearsal size
     "cfg5-small": (200_000, 20_000, 10_000_000, 128),     # BASELINE configs[4] shape / 50: full model, k = 128
+    "cfg5": (10_000_000, 1_000_000, 1_000_000_000, 128),  # BASELINE configs[4] at full size on ONE GPU (~170 GB)
     "k80": (100_000, 10_000, 5_000_000, 80),              # rehearsal size at other ranks (KB = 5, 6, 10)
     "k96": (100_000, 10_000, 5_000_000, 96),
     "k160": (100_000, 10_000, 5_000_000, 160),
@@ -256,7 +257,7 @@ def main():
     t_setup = time.perf_counter()
     # rank 0 generates, everybody receives the same bytes (robust against RNG differences)
     use_graph = (not args.no_graph) and args.size not in ("cfg2", "cfg3")
-    features = gen_features(n, 3004) if args.size in ("cfg3", "cfg5-small") else None
+    features = gen_features(n, 3004) if args.size in ("cfg3", "cfg5-small", "cfg5") else None
     if rank == 0:
         csr, csc = gen_ratings(dev, m, n, nnz, seed=1004)
         S = gen_graph(dev, n, seed=2004) if use_graph else None
@@ -283,7 +284,7 @@ def main():
 
     n_total = args.warmup + args.steps
     cfg = ALSConfig(core=CoreConfig(n_factors=k, n_iters=n_total, lambda_u=5.0, lambda_v=6.0, random_state=42,
-                                    pop_reg_mode="inverse_sqrt" if args.size == "cfg5-small" else None),
+                                    pop_reg_mode="inverse_sqrt" if args.size in ("cfg5-small", "cfg5") else None),
                     biases=BiasesConfig(lambda_bu=3.0, lambda_bi=2.0),
                     graph=(GraphConfig(alpha=0.5, sim=GraphSimConfig(source="precomputed", topk=50))
                            if S is not None else GraphConfig()))
@@ -338,7 +339,8 @@ def main():
         # Primary view: HBM.  With the Gram on the bf16 matrix cores the binding resources of this kernel are
         # the gather of 256-B factor rows (V-step launch: U does not fit the caches) and VALU issue (U-step
         # launch); the fp32-matrix view (k = 64 was fp32-MFMA-bound) is kept as `mfma_view`.
-        roof = {"kernel": "k_row_tasks<KB=4> (als_row_solve; U-step and V-step launches)",
+        roof = {"kernel": f"k_row_tasks<KB={-(-k // 16)}> (als_row_solve; U-step and V-step launches"
+                          + ("; short rows of the U-step in k_row_dual" if k > 64 else "") + ")",
                 "bound": "hbm", "achieved": by / t_rs / 1e9, "peak": 8000.0, "unit": "GB/s",
                 "frac": by / t_rs / 1e9 / 8000.0,
                 "avg_launch_ms": 1e3 * t_rs / n_launch,
