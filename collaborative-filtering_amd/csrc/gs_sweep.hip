@@ -8,6 +8,7 @@
 // Items of one level ("Level schedule") do not neighbour each
 // other, so one launch solves a whole level with one wavefront per item:
 //   b = rhs_i + alpha * sum_j S_ij V_j ;  V_i = (L L^T)^{-1} b ;  bias update.
+#include <cstdlib>
 #include "als_device.hpp"
 #include "als_hip.h"
 
@@ -176,28 +177,36 @@ __device__ __forceinline__ void st_agent(float* p, float v) {
     __hip_atomic_store(reinterpret_cast<int*>(p), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int KB>
-struct DfCfg {   // k <= 64: factor column in registers, 4 waves per workgroup; k > 64: one wave per
-                 // workgroup with the item's factor staged as a [KP][KP+1] LDS image before the waits
-    static constexpr int WPW = (KB <= 4) ? 4 : 1;
+// k <= 64: factor column in registers, 4 waves per workgroup.  k > 64, two forms:
+//   image  (STREAM = false) one wave per workgroup, the item's factor staged as a [KP][KP+1] LDS image before
+//          the waits - shortest hop (chain-bound sweeps), but 67 KB per wave leave 2 waves per CU;
+//   stream (STREAM = true)  no LDS, the factor streams from memory during the substitutions, 4 waves per
+//          workgroup, 8 per CU - 4x the items in flight, for sweeps far wider than the resident waves
+//          (10^6 items at k = 128: throughput-, not chain-bound).
+template <int KB, bool STREAM>
+struct DfCfg {
+    static constexpr bool IMAGE = KB > 4 && !STREAM;
+    static constexpr int WPW = IMAGE ? 1 : 4;
     static constexpr int LD = KCfg<KB>::KP + 1;
-    static constexpr int IMG = (KB <= 4) ? 1 : KCfg<KB>::KP * LD + 3 * KCfg<KB>::KP;
+    static constexpr int IMG = IMAGE ? KCfg<KB>::KP * LD + 3 * KCfg<KB>::KP : 1;
 };
 
-template <int KB>
-__global__ __launch_bounds__(64 * DfCfg<KB>::WPW, (KB <= 4) ? 2 : 1)
+template <int KB, bool STREAM>
+__global__ __launch_bounds__((64 * DfCfg<KB, STREAM>::WPW), (DfCfg<KB, STREAM>::IMAGE ? 1 : 2))
 void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, float* pub,
                    int32_t* err, int64_t nitems, int nwaves) {
     using C = KCfg<KB>;
     constexpr int KP = C::KP, NR = C::NR;
-    constexpr int LD = DfCfg<KB>::LD;
-    constexpr unsigned long long SPIN_LIMIT = 1ull << 28;      // ~0.12 s of shader clock
-    __shared__ float lds_img[DfCfg<KB>::IMG];
+    using D = DfCfg<KB, STREAM>;
+    constexpr int LD = D::LD;
+    constexpr bool IMAGE = D::IMAGE;
+    constexpr unsigned long long SPIN_LIMIT = 1ull << 28;      // ~2.7 s of the 100 MHz memtime clock
+    __shared__ float lds_img[D::IMG];
     float* Al = lds_img;
-    float* vec = lds_img + ((KB <= 4) ? 0 : KP * LD);
-    float* dinv = vec + ((KB <= 4) ? 0 : 2 * KP);
+    float* vec = lds_img + (IMAGE ? KP * LD : 0);
+    float* dinv = vec + (IMAGE ? 2 * KP : 0);
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * DfCfg<KB>::WPW + (threadIdx.x >> 6);
+    const int gw = blockIdx.x * D::WPW + (threadIdx.x >> 6);
     int ic[NR], col[NR];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
@@ -220,7 +229,7 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
 #pragma unroll
             for (int p = 0; p < KP; ++p) a[p] = M[p * KP + ic[0]];
             di0 = M[ic[0] * KP + ic[0]];
-        } else {
+        } else if constexpr (IMAGE) {
             // k > 64: the whole factor (M = L + L^T, 1/diag on the diagonal: row p is also column p) goes
             // into this wave's LDS image now, underneath the waits, 8 row loads in flight
             for (int p0 = 0; p0 < KP; p0 += 8) {
@@ -364,6 +373,10 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
         float x[NR], y[NR];
         if constexpr (KB <= 4) {
             x[0] = solve_regs<KP>(a, di0, rhs_i[0] + P.alpha * g[0], lane, &y[0]);
+        } else if constexpr (!IMAGE) {
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) x[rr] = rhs_i[rr] + P.alpha * g[rr];
+            solve_stream<KB>(M, x, lane, y);
         } else {
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr)
@@ -411,31 +424,47 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
     }
 }
 
-template <int KB>
-int launch_gs_dataflow(const als_gs_sweep_params* p, const int32_t* Sw, float* pub,
-                       int32_t* err, int64_t nitems, hipStream_t st) {
+template <int KB, bool STREAM>
+int launch_gs_dataflow_as(const als_gs_sweep_params* p, const int32_t* Sw, float* pub,
+                          int32_t* err, int64_t nitems, hipStream_t st, int* waves_out) {
     // Every wave of the launch must be co-resident (a non-resident workgroup would never start while the
     // resident ones wait for its items): the grid is sized from the occupancy the runtime reports for this
     // kernel - registers and LDS included - times the number of CUs, capped at 8 waves per CU.
-    // (k <= 64: 4-wave workgroups, 2 per CU under the launch bound; k > 64: one-wave workgroups, as many per
-    // CU as their LDS images fit.)
-    constexpr int WPW = DfCfg<KB>::WPW;
+    constexpr int WPW = DfCfg<KB, STREAM>::WPW;
     static int per_cu = 0, ncu = 0;
     if (per_cu == 0) {
         int dev = 0, nb = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gs_dataflow<KB>, 64 * WPW, 0) != hipSuccess || nb < 1)
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gs_dataflow<KB, STREAM>, 64 * WPW, 0) != hipSuccess ||
+            nb < 1)
             return ALS_E_LAUNCH;
         ncu = prop.multiProcessorCount;
         per_cu = nb * WPW > 8 ? 8 / WPW : nb;
         if (per_cu < 1) per_cu = 1;
     }
+    if (waves_out) { *waves_out = ncu * per_cu * WPW; return 0; }
     int nwg = ncu * per_cu;
     if ((int64_t)nwg * WPW > nitems) nwg = (int)((nitems + WPW - 1) / WPW);
     if (nwg < 1) return 0;
-    hipLaunchKernelGGL(k_gs_dataflow<KB>, dim3(nwg), dim3(64 * WPW), 0, st, *p, Sw, pub, err, nitems, nwg * WPW);
+    hipLaunchKernelGGL((k_gs_dataflow<KB, STREAM>), dim3(nwg), dim3(64 * WPW), 0, st, *p, Sw, pub, err, nitems,
+                       nwg * WPW);
     return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
+}
+
+template <int KB>
+int launch_gs_dataflow(const als_gs_sweep_params* p, const int32_t* Sw, float* pub,
+                       int32_t* err, int64_t nitems, hipStream_t st) {
+    if constexpr (KB > 4) {
+        // far more items than the image form keeps in flight: the sweep is throughput-bound, stream the factor
+        int image_waves = 0;
+        const int rc = launch_gs_dataflow_as<KB, false>(p, Sw, pub, err, nitems, st, &image_waves);
+        if (rc != 0) return rc;
+        static const char* force = getenv("ALS_GS_FORM");           // "stream" / "image": tests and experiments
+        const bool stream = force ? (force[0] == 's') : nitems > (int64_t)256 * image_waves;
+        if (stream) return launch_gs_dataflow_as<KB, true>(p, Sw, pub, err, nitems, st, nullptr);
+    }
+    return launch_gs_dataflow_as<KB, false>(p, Sw, pub, err, nitems, st, nullptr);
 }
 
 template <int KB>

@@ -9,6 +9,7 @@ factors in fp32 and accumulates Gram / Cholesky in fp32, statistics in fp64):
   biases, mu                 atol 2e-4
   iteration count (early stop) identical
 """
+import os
 import numpy as np
 import pytest
 
@@ -318,3 +319,40 @@ def test_hip_graph_replay_is_bitwise_the_eager_fit(name):
     assert a.mu == b.mu
     for f in g.cfg["feats"]:
         np.testing.assert_array_equal(a.W[f], b.W[f])
+
+
+def test_streamed_sweep_form_equals_the_image_form(tmp_path):
+    """k > 64 has two forms of the dataflow sweep (factor as an LDS image / streamed during the solve); the
+    library picks by the number of items.  The streamed form is forced in a child process (ALS_GS_FORM) and
+    must reproduce the image form's fit: same dependency semantics and summation order, only the
+    substitution's operand source differs."""
+    _cuda()
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from collaborative_filtering_amd import ALS, ALSConfig, BiasesConfig, CoreConfig, GraphConfig, GraphSimConfig, layout
+from tests.synth import make_features, make_ratings
+k, m, n = 128, 400, 300
+r, c, v = make_ratings(m, n, 9000, seed=628)
+G, _ = make_features(n, 9)
+S_csr = layout.dense_graph_to_csr(layout.build_similarity_dense(G, 8, 1e-8))
+cfg = ALSConfig(core=CoreConfig(n_factors=k, n_iters=4, lambda_u=3.0, lambda_v=4.0, pop_reg_mode="inverse_sqrt"),
+                biases=BiasesConfig(lambda_bu=2.0, lambda_bi=1.5),
+                graph=GraphConfig(alpha=0.8, sim=GraphSimConfig(source="precomputed")))
+model = ALS(cfg).fit_coo(r, c, v, (m, n), tol=None, verbose=0, S=S_csr)
+np.savez(sys.argv[1], V=model.V, U=model.U, b_i=model.b_i, rmse=np.asarray(model.history["train_rmse"]))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    outs = {}
+    for form in ("image", "stream"):
+        out = str(tmp_path / f"{form}.npz")
+        env = dict(os.environ, ALS_GS_FORM=form)
+        res = subprocess.run([sys.executable, "-c", script, out], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs[form] = np.load(out)
+    a, b = outs["image"], outs["stream"]
+    scale = float(np.abs(a["V"]).max())
+    np.testing.assert_allclose(b["V"], a["V"], rtol=0, atol=2e-5 * scale)
+    np.testing.assert_allclose(b["U"], a["U"], rtol=0, atol=2e-5 * float(np.abs(a["U"]).max()))
+    np.testing.assert_allclose(b["rmse"], a["rmse"], rtol=0, atol=2e-6)
