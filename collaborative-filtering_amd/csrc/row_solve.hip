@@ -201,18 +201,20 @@ __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __
     int nflush = 0;
     // software pipeline over 64-rating chunks: indices two chunks ahead,
     // value + opposite-side bias one chunk ahead of the factor-row gathers
-    int idx1 = (lane < len) ? idxp[lane] : zero_row;
-    int idx2 = (64 + lane < len) ? idxp[64 + lane] : zero_row;
-    float val1 = (lane < len) ? valp[lane] : 0.f;
+    // indices / values are read once: non-temporal, so that they do not push the gathered factor rows (244 MiB of
+    // U at cfg 4, just under the 256 MiB Infinity Cache) out of the last-level cache
+    int idx1 = (lane < len) ? __builtin_nontemporal_load(idxp + lane) : zero_row;
+    int idx2 = (64 + lane < len) ? __builtin_nontemporal_load(idxp + 64 + lane) : zero_row;
+    float val1 = (lane < len) ? __builtin_nontemporal_load(valp + lane) : 0.f;
     float bo1 = (lane < len) ? bias_other[idx1] : 0.f;
     for (int base = 0; base < len; base += 64) {
         const int idx0 = idx1;
         const float val0 = val1, bo0 = bo1;
         idx1 = idx2;
         const int t2 = base + 128 + lane;
-        idx2 = (t2 < len) ? idxp[t2] : zero_row;
+        idx2 = (t2 < len) ? __builtin_nontemporal_load(idxp + t2) : zero_row;
         const int t1 = base + 64 + lane;
-        val1 = (t1 < len) ? valp[t1] : 0.f;
+        val1 = (t1 < len) ? __builtin_nontemporal_load(valp + t1) : 0.f;
         bo1 = (t1 < len) ? bias_other[idx1] : 0.f;
         const int nvalid = min(64, len - base);
         const bool ok = lane < nvalid;
@@ -550,7 +552,7 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
                                       ((((p >> 2) & 3) ^ ((rowv >> 2) & 3)) << 2) + (p & 3)];
                 const int rsafe = max(p, ic & ~15);
                 const float lcolv = Ls[colb + rsafe * 16 + (((c >> 2) ^ ((rsafe >> 2) & 3)) << 2)];
-                if (i < KP) M[p * KP + i] = (p == i) ? S.di[rr] : (p < i ? lrow : lcolv);
+                if (i < KP) __builtin_nontemporal_store((p == i) ? S.di[rr] : (p < i ? lrow : lcolv), M + p * KP + i);
             }
         }
         return;
