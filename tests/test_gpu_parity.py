@@ -300,7 +300,7 @@ def test_device_graph_build_in_fit():
     np.testing.assert_allclose(a.V, b.V, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["g2_bias_pop", "g4_feat_uw2", "g5_graph_a0.5", "g6_early_stop"])
+@pytest.mark.parametrize("name", ["g2_bias_pop", "g4_feat_uw2", "g5_graph_a0.5", "g6_early_stop", "g7_k128"])
 def test_hip_graph_replay_is_bitwise_the_eager_fit(name):
     """hip_graph=True: iterations after the first are replayed as captured HIP graphs (one per W-step /
     no-W-step variant).  Same launches, same order: every result must be bitwise equal to the eager fit,
