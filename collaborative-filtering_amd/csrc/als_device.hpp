@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -40,10 +41,23 @@ constexpr unsigned long long lanes_below() {
     return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
 }
 
+// Sum over the 64 lanes, result in every lane (wave-uniform).  DPP adds inside the 16-lane rows (xor 1, xor 2,
+// half-row mirror, row mirror - a sum does not care which partner), row_bcast15 / row_bcast31 across the rows,
+// one v_readlane of lane 63: 6 VALU + 1 readlane instead of 6 x (ds_bpermute + index arithmetic + add).
+// The order of the additions is fixed, so the result is reproducible.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    auto dpp = [](float x, auto ctrl, auto rows) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value,
+                                                          decltype(rows)::value, 0xf, false));
+    };
+    using std::integral_constant;
+    v += dpp(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});     // quad_perm [1,0,3,2]
+    v += dpp(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});     // quad_perm [2,3,0,1]
+    v += dpp(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});    // row_half_mirror
+    v += dpp(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});    // row_mirror: every lane = row sum
+    v += dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});    // row_bcast15 into rows 1, 3
+    v += dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});    // row_bcast31 into rows 2, 3
+    return readlane_f(v, 63);
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

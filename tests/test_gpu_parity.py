@@ -353,6 +353,7 @@ np.savez(sys.argv[1], V=model.V, U=model.U, b_i=model.b_i, rmse=np.asarray(model
         outs[form] = np.load(out)
     a, b = outs["image"], outs["stream"]
     scale = float(np.abs(a["V"]).max())
-    np.testing.assert_allclose(b["V"], a["V"], rtol=0, atol=2e-5 * scale)
-    np.testing.assert_allclose(b["U"], a["U"], rtol=0, atol=2e-5 * float(np.abs(a["U"]).max()))
+    # two fp32 substitution codes on the same factor: agreement well inside the fixture tolerance (2e-4 * max)
+    np.testing.assert_allclose(b["V"], a["V"], rtol=0, atol=1e-4 * scale)
+    np.testing.assert_allclose(b["U"], a["U"], rtol=0, atol=1e-4 * float(np.abs(a["U"]).max()))
     np.testing.assert_allclose(b["rmse"], a["rmse"], rtol=0, atol=2e-6)
