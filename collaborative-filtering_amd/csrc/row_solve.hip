@@ -288,6 +288,25 @@ struct Chol {
 
 // one pivot of panel J (column 16J + T): scale the column, ride the forward
 // substitution along, update the remaining columns of the panel
+// p[.][t2] += nl * L[16J+t2][T] for t2 = T2 ... 15 (nl = -l); the multiplier is lane t2 of every 16-lane row of
+// lrep and is picked up by the FMA itself (v_fmac_f32_dpp row_newbcast:t2).  The compiler only emits DPP on
+// v_mov here (its DPP combiner has no VOP3 v_fma form on gfx9), so the VOP2 form is written out; the leading
+// s_nop covers the VALU-write -> DPP-read wait states the hazard recogniser cannot see inside asm.
+template <int KB, int T2, bool FIRST>
+__device__ __forceinline__ void panel_trailing(float (&p)[KCfg<KB>::NR][16], const float (&nl)[KCfg<KB>::NR], float lrep) {
+    if constexpr (T2 < 16) {
+#pragma unroll
+        for (int rr = 0; rr < KCfg<KB>::NR; ++rr) {
+            if (FIRST && rr == 0)
+                asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                    : "+v"(p[rr][T2]) : "v"(lrep), "v"(nl[rr]), "n"(T2));
+            else
+                asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                    : "+v"(p[rr][T2]) : "v"(lrep), "v"(nl[rr]), "n"(T2));
+        }
+        panel_trailing<KB, T2 + 1, false>(p, nl, lrep);
+    }
+}
 template <int KB, int J, int T, bool SOLVE>
 __device__ __forceinline__ void panel_pivot(float (&p)[KCfg<KB>::NR][16], Chol<KB>& S, int lane) {
     constexpr int NR = KCfg<KB>::NR;
@@ -299,18 +318,17 @@ __device__ __forceinline__ void panel_pivot(float (&p)[KCfg<KB>::NR][16], Chol<K
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) { l[rr] = p[rr][T] * inv; p[rr][T] = l[rr]; }
     S.di[RP] = select_lanes<1ull << LP>(inv, S.di[RP]);
-    // multipliers L[16J+t2][16J+T] first (wave-uniform, in SGPRs), then the FMAs: keeps the
-    // v_readlane -> SGPR -> VALU hazard slots filled with independent work
-    float s[16 - T > 1 ? 15 - T : 1];
-#pragma unroll
-    for (int t2 = T + 1; t2 < 16; ++t2)
-        s[t2 - T - 1] = readlane_f(l[(16 * J + t2) >> 6], (16 * J + t2) & 63);
+    // multipliers L[16J+t2][16J+T]: the scaled pivot column of the diagonal block (lanes 16J ... 16J+15) is
+    // replicated into every 16-lane row once (one ds_bpermute), after which each FMA picks its multiplier
+    // with a DPP row_newbcast:t2 operand - no v_readlane per multiplier
+    constexpr int DR = (16 * J) >> 6, DL = (16 * J) & 63;
+    const float lrep = bperm_f(l[DR], DL + (lane & 15));
     float yt = 0.f;
     if constexpr (SOLVE) yt = readlane_f(S.b[RP], LP) * inv;
+    float nl[NR];
 #pragma unroll
-    for (int t2 = T + 1; t2 < 16; ++t2)
-#pragma unroll
-        for (int rr = 0; rr < NR; ++rr) p[rr][t2] = fmaf(-l[rr], s[t2 - T - 1], p[rr][t2]);
+    for (int rr = 0; rr < NR; ++rr) nl[rr] = -l[rr];
+    panel_trailing<KB, T + 1, true>(p, nl, lrep);
     if constexpr (SOLVE) {
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) S.b[rr] = fmaf(-l[rr], yt, S.b[rr]);
