@@ -290,27 +290,26 @@ struct Chol {
 // substitution along, update the remaining columns of the panel
 // p[.][t2] += nl * L[16J+t2][T] for t2 = T2 ... 15 (nl = -l); the multiplier is lane t2 of every 16-lane row of
 // lrep and is picked up by the FMA itself (v_fmac_f32_dpp row_newbcast:t2).  The compiler only emits DPP on
-// v_mov here (its DPP combiner has no VOP3 v_fma form on gfx9), so the VOP2 form is written out; the leading
-// s_nop covers the VALU-write -> DPP-read wait states the hazard recogniser cannot see inside asm.
-template <int KB, int T2, bool FIRST>
+// v_mov here (its DPP combiner has no VOP3 v_fma form on gfx9), so the VOP2 form is written out; the caller
+// orders an s_nop between the write of lrep and these reads (wait states the hazard recogniser cannot see).
+template <int KB, int T2>
 __device__ __forceinline__ void panel_trailing(float (&p)[KCfg<KB>::NR][16], const float (&nl)[KCfg<KB>::NR], float lrep) {
     if constexpr (T2 < 16) {
 #pragma unroll
-        for (int rr = 0; rr < KCfg<KB>::NR; ++rr) {
-            if (FIRST && rr == 0)
-                asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                    : "+v"(p[rr][T2]) : "v"(lrep), "v"(nl[rr]), "n"(T2));
-            else
-                asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                    : "+v"(p[rr][T2]) : "v"(lrep), "v"(nl[rr]), "n"(T2));
-        }
-        panel_trailing<KB, T2 + 1, false>(p, nl, lrep);
+        for (int rr = 0; rr < KCfg<KB>::NR; ++rr)
+            asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                : "+v"(p[rr][T2]) : "v"(lrep), "v"(nl[rr]), "n"(T2));
+        panel_trailing<KB, T2 + 1>(p, nl, lrep);
     }
 }
 template <int KB, int J, int T, bool SOLVE>
 __device__ __forceinline__ void panel_pivot(float (&p)[KCfg<KB>::NR][16], Chol<KB>& S, int lane) {
     constexpr int NR = KCfg<KB>::NR;
     constexpr int PIV = 16 * J + T, RP = PIV >> 6, LP = PIV & 63;
+    constexpr int DR = (16 * J) >> 6, DL = (16 * J) & 63;
+    // unscaled pivot column of the diagonal block, replicated into every 16-lane row: issued before the
+    // rsqrt chain so the LDS round trip overlaps it (and the previous pivot's FMAs)
+    const float prep = bperm_f(p[DR][T], DL + (lane & 15));
     const float d = readlane_f(p[RP][T], LP);
     S.spd = S.spd && (d > 0.f);
     const float inv = __builtin_amdgcn_rsqf(d);            // v_rsq_f32: 1 ulp, ample for the fp32 tolerance
@@ -318,17 +317,16 @@ __device__ __forceinline__ void panel_pivot(float (&p)[KCfg<KB>::NR][16], Chol<K
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) { l[rr] = p[rr][T] * inv; p[rr][T] = l[rr]; }
     S.di[RP] = select_lanes<1ull << LP>(inv, S.di[RP]);
-    // multipliers L[16J+t2][16J+T]: the scaled pivot column of the diagonal block (lanes 16J ... 16J+15) is
-    // replicated into every 16-lane row once (one ds_bpermute), after which each FMA picks its multiplier
-    // with a DPP row_newbcast:t2 operand - no v_readlane per multiplier
-    constexpr int DR = (16 * J) >> 6, DL = (16 * J) & 63;
-    const float lrep = bperm_f(l[DR], DL + (lane & 15));
+    // multipliers L[16J+t2][16J+T] = lane t2 of every 16-lane row of lrep: each FMA picks its own with a DPP
+    // row_newbcast:t2 operand - no v_readlane per multiplier
+    float lrep = prep * inv;
+    asm("s_nop 1" : "+v"(lrep));        // VALU write -> DPP read: 2 wait states, invisible to the hazard recogniser
     float yt = 0.f;
     if constexpr (SOLVE) yt = readlane_f(S.b[RP], LP) * inv;
     float nl[NR];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) nl[rr] = -l[rr];
-    panel_trailing<KB, T + 1, true>(p, nl, lrep);
+    panel_trailing<KB, T + 1>(p, nl, lrep);
     if constexpr (SOLVE) {
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) S.b[rr] = fmaf(-l[rr], yt, S.b[rr]);
