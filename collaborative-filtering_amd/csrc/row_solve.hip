@@ -283,23 +283,35 @@ struct Chol {
     float di[NR];       // 1 / L[i][i] of the lane's rows i = lane + 64*rr
     float y[NR];        // forward-solved right-hand side (when SOLVE)
     float b[NR];        // running right-hand side
-    bool spd;
 };
+
+// positive definiteness, checked once after the factorisation: pivot d <= 0 (or NaN) leaves rsq(d) = inf / NaN
+// in di, and everything computed after it is NaN as well - no per-pivot compare needed
+template <int KB>
+__device__ __forceinline__ bool chol_spd(const Chol<KB>& S, int lane) {
+    bool bad = false;
+#pragma unroll
+    for (int rr = 0; rr < KCfg<KB>::NR; ++rr) {
+        const float v = S.di[rr];
+        bad = bad || ((lane + 64 * rr < KCfg<KB>::KP) && !(v > 0.f && v < __builtin_inff()));
+    }
+    return __builtin_amdgcn_ballot_w64(bad) == 0;
+}
 
 // one pivot of panel J (column 16J + T): scale the column, ride the forward
 // substitution along, update the remaining columns of the panel
-// p[.][t2] += nl * L[16J+t2][T] for t2 = T2 ... 15 (nl = -l); the multiplier is lane t2 of every 16-lane row of
+// p[.][t2] += l * (-L[16J+t2][T]) for t2 = T2 ... 15; the negated multiplier is lane t2 of every 16-lane row of
 // lrep and is picked up by the FMA itself (v_fmac_f32_dpp row_newbcast:t2).  The compiler only emits DPP on
 // v_mov here (its DPP combiner has no VOP3 v_fma form on gfx9), so the VOP2 form is written out; the caller
 // orders an s_nop between the write of lrep and these reads (wait states the hazard recogniser cannot see).
 template <int KB, int T2>
-__device__ __forceinline__ void panel_trailing(float (&p)[KCfg<KB>::NR][16], const float (&nl)[KCfg<KB>::NR], float lrep) {
+__device__ __forceinline__ void panel_trailing(float (&p)[KCfg<KB>::NR][16], const float (&l)[KCfg<KB>::NR], float lrep) {
     if constexpr (T2 < 16) {
 #pragma unroll
         for (int rr = 0; rr < KCfg<KB>::NR; ++rr)
             asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                : "+v"(p[rr][T2]) : "v"(lrep), "v"(nl[rr]), "n"(T2));
-        panel_trailing<KB, T2 + 1>(p, nl, lrep);
+                : "+v"(p[rr][T2]) : "v"(lrep), "v"(l[rr]), "n"(T2));
+        panel_trailing<KB, T2 + 1>(p, l, lrep);
     }
 }
 template <int KB, int J, int T, bool SOLVE>
@@ -311,7 +323,6 @@ __device__ __forceinline__ void panel_pivot(float (&p)[KCfg<KB>::NR][16], Chol<K
     // rsqrt chain so the LDS round trip overlaps it (and the previous pivot's FMAs)
     const float prep = bperm_f(p[DR][T], DL + (lane & 15));
     const float d = readlane_f(p[RP][T], LP);
-    S.spd = S.spd && (d > 0.f);
     const float inv = __builtin_amdgcn_rsqf(d);            // v_rsq_f32: 1 ulp, ample for the fp32 tolerance
     float l[NR];
 #pragma unroll
@@ -319,14 +330,11 @@ __device__ __forceinline__ void panel_pivot(float (&p)[KCfg<KB>::NR][16], Chol<K
     S.di[RP] = select_lanes<1ull << LP>(inv, S.di[RP]);
     // multipliers L[16J+t2][16J+T] = lane t2 of every 16-lane row of lrep: each FMA picks its own with a DPP
     // row_newbcast:t2 operand - no v_readlane per multiplier
-    float lrep = prep * inv;
+    float lrep = -(prep * inv);          // the sign of the update rides on the replicated column
     asm("s_nop 1" : "+v"(lrep));        // VALU write -> DPP read: 2 wait states, invisible to the hazard recogniser
     float yt = 0.f;
     if constexpr (SOLVE) yt = readlane_f(S.b[RP], LP) * inv;
-    float nl[NR];
-#pragma unroll
-    for (int rr = 0; rr < NR; ++rr) nl[rr] = -l[rr];
-    panel_trailing<KB, T + 1>(p, nl, lrep);
+    panel_trailing<KB, T + 1>(p, l, lrep);
     if constexpr (SOLVE) {
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) S.b[rr] = fmaf(-l[rr], yt, S.b[rr]);
@@ -501,7 +509,6 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
     Chol<KB> S;
     float csrow[NR];
     int colrow[NR];
-    S.spd = true;
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
         float bsel = 0.f, csel = 0.f;
@@ -552,7 +559,7 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
 
     if (P.factor_out) {
         chol_panels<KB, 0, false>(A, S, Ls, lane);
-        if (!S.spd && lane == 0) atomicMax(P.status, row + 1);
+        if (!chol_spd<KB>(S, lane) && lane == 0) atomicMax(P.status, row + 1);
         // symmetric completion of L with 1/L_ii on the diagonal, perm space:
         // M[p][i] = L[i][p] (p < i), L[p][i] (p > i)
         float* M = P.factor_out + r64 * KP * KP;
@@ -582,8 +589,10 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
         for (int rr = 0; rr < NR; ++rr)
             if (lane + 64 * rr < KP) S.b[rr] += P.rhs_extra[r64 * P.ld + colrow[rr]];
     }
-    if (!(P.reserved0 & 2)) chol_panels<KB, 0, true>(A, S, Ls, lane);
-    if (!S.spd && lane == 0) atomicMax(P.status, row + 1);
+    if (!(P.reserved0 & 2)) {
+        chol_panels<KB, 0, true>(A, S, Ls, lane);
+        if (!chol_spd<KB>(S, lane) && lane == 0) atomicMax(P.status, row + 1);
+    }
     float x[NR];
     if (!(P.reserved0 & 4)) backward_solve<KB>(Ls, S, x, lane);
     else {
@@ -762,9 +771,8 @@ __device__ __forceinline__ void row_dual(const als_row_solve_params& P, int row,
     Chol<NB> S;
 #pragma unroll
     for (int ss = 0; ss < NS; ++ss) { S.b[ss] = r_l[ss]; S.di[ss] = 0.f; S.y[ss] = 0.f; }
-    S.spd = true;
     chol_panels<NB, 0, true>(A, S, Ls, lane);
-    if (!S.spd && lane == 0) atomicMax(P.status, row + 1);
+    if (!chol_spd<NB>(S, lane) && lane == 0) atomicMax(P.status, row + 1);
     float w[NS];
     backward_solve<NB>(Ls, S, w, lane);               // w_t in lane t & 63, slot t >> 6 (0 past len)
 
