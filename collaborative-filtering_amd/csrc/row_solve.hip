@@ -327,7 +327,6 @@ __device__ __forceinline__ void panel_pivot(float (&p)[KCfg<KB>::NR][16], Chol<K
     float l[NR];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) { l[rr] = p[rr][T] * inv; p[rr][T] = l[rr]; }
-    S.di[RP] = select_lanes<1ull << LP>(inv, S.di[RP]);
     // multipliers L[16J+t2][16J+T] = lane t2 of every 16-lane row of lrep: each FMA picks its own with a DPP
     // row_newbcast:t2 operand - no v_readlane per multiplier
     float lrep = -(prep * inv);          // the sign of the update rides on the replicated column
@@ -396,6 +395,13 @@ __device__ __forceinline__ void chol_panel(RowAcc<KB>& A, Chol<KB>& S, float* __
         }
     }
     wave_lds_sync();
+    // 1 / L_ii of the 16 pivots of this panel, once per panel: lane 16J + c reads its own diagonal entry back
+    // (row c of the block column, swizzle group (c >> 2) ^ (c >> 2) = 0) instead of one select per pivot
+    {
+        constexpr int DR = (16 * J) >> 6, DL = (16 * J) & 63;
+        const float dl = Ls[OFF + c * 16 + (c & 3)];
+        S.di[DR] = select_lanes<0xFFFFull << DL>(__builtin_amdgcn_rcpf(dl), S.di[DR]);
+    }
     // 5. trailing update on the matrix cores: acc(I,K) -= L_IJ * L_KJ^T for J < K <= I.
     //    Lane (c,q) reads L[16I + c][16J + 4q .. 4q+3]: element e is the operand of MFMA step e
     //    (contraction index 4q + e on both operands).
