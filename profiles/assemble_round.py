@@ -10,7 +10,7 @@ os.chdir(root)
 b = json.loads(open(f"gpurun_out/{tag}_bench.json").read().strip().splitlines()[-1])
 json.dump(b, open(f"profiles/{tag}_bench.json", "w"))
 other = {}
-for sname in ("cfg2", "cfg3", "cfg5-small"):
+for sname in ("cfg2", "cfg3", "cfg5-small", "k80", "k96", "k160"):
     fn = f"gpurun_out/{tag}_{sname}.json"
     if not os.path.exists(fn):
         continue
