@@ -1,7 +1,7 @@
 """Static check of the hand-written DPP instructions in the built gfx950 code object.
 
-The Cholesky panel of als_row_solve issues `v_fmac_f32_dpp ... row_newbcast:t` from inline asm
-(collaborative-filtering_amd/csrc/row_solve.hip, panel_trailing).  The compiler's hazard recogniser does not look
+The Cholesky panel of als_row_solve issues `v_fmac_f32_dpp` / `v_mul_f32_dpp ... row_newbcast:t` from inline asm
+(collaborative-filtering_amd/csrc/row_solve.hip, panel_pivot / panel_trailing).  The compiler's hazard recogniser does not look
 into asm, so the two wait states gfx9 requires between a VALU write of a VGPR and a DPP read of it are ordered
 by hand (an `s_nop 1` tied to the operand).  This test disassembles libals_hip.so and verifies, for every such
 instruction, that no VALU instruction wrote its DPP source within the two preceding wait states and that no
@@ -63,7 +63,7 @@ def _check(text):
             window = []
             continue
         assert not ins.startswith("v_cmpx"), "v_cmpx writes EXEC from the VALU: DPP ops need 5 wait states after it"
-        if ins.startswith("v_fmac_f32_dpp"):
+        if "row_newbcast" in ins:           # only the hand-written asm uses this DPP control
             ndpp += 1
             ops = ins.split(None, 1)[1].split(",")
             src = _vgprs(ops[1].split()[0])
@@ -72,7 +72,7 @@ def _check(text):
             for prev in reversed(window):
                 if covered >= 2:
                     break
-                if prev.startswith("v_") and not prev.startswith("v_fmac_f32_dpp"):
+                if prev.startswith("v_"):
                     dst = _vgprs(prev.split(None, 1)[1].split(",")[0])
                     assert not (dst & src), f"DPP hazard: `{prev}` then `{ins}` within 2 wait states"
                 m = re.match(r"s_nop (\d+)", prev)
