@@ -98,7 +98,9 @@ def test_checker_sees_a_hazard_and_accepts_the_ordered_form():
 
 @pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump of the ROCm image not present")
 def test_dpp_reads_are_two_wait_states_behind_their_valu_writes(tmp_path):
-    assert os.path.exists(LIB), "build the library first (python -c 'import __graft_entry__ as g; g.build()')"
+    if not os.path.exists(LIB):             # fresh checkout: the .so is git-ignored
+        import __graft_entry__ as ge
+        ge.build()
     texts = _disassemble(tmp_path)
     assert texts, "no gfx950 code object in libals_hip.so"
     ndpp = sum(_check(t) for t in texts)
