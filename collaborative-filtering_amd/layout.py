@@ -91,7 +91,12 @@ def dual_max_len(k: int) -> int:
     """Longest row the engine solves in the dual form at rank k: at most 64 ratings for k > 64 (n x n instead
     of k x k system, 5x fewer cycles per row at k = 128).  For k <= 64 the kernel supports it too (rows with
     fewer 16-rating blocks than k/16), but at k = 64 it measured the same as the primal kernel (U-step 7.68 ms
-    either way), so the engine leaves those rows primal."""
+    either way; after the panel trimming of round 1: 6.68 primal vs 6.84 / 6.55 / 6.64 with rows of up to 16 /
+    32 / 48 ratings dual - run-to-run noise), so the engine leaves those rows primal.  ALS_DUAL_LEN overrides."""
+    import os
+    env = os.environ.get("ALS_DUAL_LEN")
+    if env is not None:                      # tuning knob (multiples of 16, < padded k)
+        return max(0, min(int(env), DUAL_MAX_LEN, padded_k(k) - 16))
     return DUAL_MAX_LEN if padded_k(k) // 16 >= 5 else 0
 
 
