@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Observed error of the HIP path against every golden fixture (the unmodified reference's outputs), per Gram
+mode / solve dtype: the numbers the tolerances of tests/test_gpu_parity.py are derived from (about 10x these).
+
+    python profiles/parity_margins.py [out.json] [name-prefix ...]
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from tests.common import Golden, golden_names      # noqa: E402
+from tests.test_gpu_parity import _model_for       # noqa: E402
+
+
+def margins(name, **kw):
+    g = Golden(name)
+    d = g.d
+    model = _model_for(g, **kw)
+    r, c, v = g.train
+    try:
+        model.fit_coo(r, c, v, (g.m, g.n), features=g.features or None, tol=g.cfg["tol"],
+                      min_iters=g.cfg["min_iters"], verbose=0)
+    except Exception as e:          # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+    out = {}
+    ref_h, got_h = d["hist_train_rmse"], np.asarray(model.history["train_rmse"])
+    out["iters"] = [int(got_h.shape[0]), int(ref_h.shape[0])]
+    nh = min(len(ref_h), len(got_h))
+    out["hist_rmse"] = float(np.max(np.abs(got_h[:nh] - ref_h[:nh])))
+    for key in ("U_norm", "V_norm", "bu_norm", "bi_norm"):
+        ref = d["hist_" + key][:nh]
+        out["rel_" + key] = float(np.max(np.abs(np.asarray(model.history[key])[:nh] - ref) / np.maximum(np.abs(ref), 1e-30)))
+    if "sel_u" in d.files:
+        U, V = model.U[d["sel_u"]], model.V[d["sel_i"]]
+    else:
+        U, V = model.U, model.V
+    for nm, got, ref in (("U", U, d["U"]), ("V", V, d["V"])):
+        out["absmax_" + nm] = float(np.max(np.abs(got - ref)) / max(np.max(np.abs(ref)), 1e-30))
+    out["b_u"] = float(np.max(np.abs(model.b_u - d["b_u"])))
+    out["b_i"] = float(np.max(np.abs(model.b_i - d["b_i"])))
+    out["mu"] = abs(model.mu - float(d["mu"][0]))
+    for f in g.cfg["feats"]:
+        ref = d["W_" + f]
+        out["absmax_W_" + f] = float(np.max(np.abs(model.W[f] - ref)) / max(np.max(np.abs(ref)), 1e-30))
+    pred = model.predict_at(g.val_flat(), g.features or None)
+    out["pred_val"] = float(np.max(np.abs(pred - d["pred_val"])))
+    rmse = float(np.sqrt(np.mean((g.val_truth() - pred) ** 2)))
+    out["test_rmse"] = abs(rmse - float(d["test_rmse"][0]))
+    return out
+
+
+def main():
+    out_path = sys.argv[1] if len(sys.argv) > 1 else None
+    prefixes = sys.argv[2:]
+    import inspect
+    from collaborative_filtering_amd import ALS
+    has_f64 = "solve_dtype" in inspect.signature(ALS.__init__).parameters
+    modes = [("bf16x3", {"gram": "bf16x3"}), ("f32", {"gram": "f32"})]
+    if has_f64:
+        modes.append(("float64", {"solve_dtype": "float64"}))
+    res = {}
+    for name in golden_names():
+        if prefixes and not any(name.startswith(p) for p in prefixes):
+            continue
+        res[name] = {}
+        for label, kw in modes:
+            res[name][label] = margins(name, **kw)
+            print(name, label, json.dumps(res[name][label]), flush=True)
+    if out_path:
+        with open(out_path, "w") as f:
+            json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

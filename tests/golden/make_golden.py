@@ -150,8 +150,17 @@ def feature_norm_case():
 
 
 def main():
-    folds_case()
-    feature_norm_case()
+    only = sys.argv[1:]            # optional fixture-name prefixes: regenerate only those
+    global run_case
+    if only:
+        _run = run_case
+
+        def run_case(name, **kw):                                  # noqa: F811
+            if any(name.startswith(p) for p in only):
+                _run(name, **kw)
+    else:
+        folds_case()
+        feature_norm_case()
     sim10 = dict(source="feature", feature_name="genres", metric="cosine",
                  topk=10, eps=1e-8)
     # g1: plain U/V (+ the always-on mu / bias terms)
@@ -191,6 +200,25 @@ def main():
     run_case("g9_k64_mid", m=400, n=50, nnz=12000, seed=109, k=64, n_iters=4,
              lambda_u=4.0, lambda_v=6.0, bu=3.0, bi=2.0,
              store_factors=False, sample_rows=50)
+    # g10: the FULL model (popularity-scaled lambda_v + bias lambdas + genres/years projections + graph
+    # Laplacian) at the wide ranks of BASELINE configs[3]/[4]: k = 64 and k = 128
+    for k in (64, 128):
+        run_case(f"g10_full_k{k}", m=300, n=200, nnz=6000, seed=110, k=k,
+                 n_iters=5, lambda_u=2.0, lambda_v=3.0, pop="inverse_sqrt",
+                 bu=1.5, bi=2.5, update_w_every=2, feats=("genres", "years"),
+                 lambda_w={"genres": 5.0, "years": 10.0}, alpha=0.5, sim=sim10,
+                 store_factors=False, sample_rows=64)
+    # g11: the edges of the tuner's search space (scripts/tune_params.py:100-101 explores lambda in
+    # [1e-4, 1e4]); most rows have fewer ratings than k, i.e. rank-deficient Grams with cond ~ 1/lambda
+    run_case("g11_lam_tuned_k64", m=300, n=200, nnz=6000, seed=111, k=64, n_iters=6,
+             lambda_u=1e3, lambda_v=1e-3, pop="inverse_sqrt", bu=3.0, bi=2.0,
+             store_factors=False, sample_rows=64)
+    run_case("g11_lam1e-2_k64", m=300, n=200, nnz=6000, seed=112, k=64, n_iters=6,
+             lambda_u=1e-2, lambda_v=1e-2, bu=3.0, bi=2.0,
+             store_factors=False, sample_rows=64)
+    run_case("g11_lam1e-4_k64", m=300, n=200, nnz=6000, seed=113, k=64, n_iters=6,
+             lambda_u=1e-4, lambda_v=1e-4, bu=3.0, bi=2.0,
+             store_factors=False, sample_rows=64)
 
 
 if __name__ == "__main__":

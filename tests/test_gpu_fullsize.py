@@ -8,6 +8,12 @@ through size-independent properties - the oracle cannot run this size in test ti
   * the fused closed-form statistics equal the standalone residual pass;
   * two fits from scratch are bitwise equal.
 
+BASELINE.json configs[4] (10M x 1M, 1B ratings, k = 128, bias + popularity-scaled lambda_v + genres / years
+projections + Laplacian) is covered the same way, at its shape / 50 (`cfg5-small`: every k = 128 code path -
+primal K1 with Gram and factor by-products, both dual-form row classes, the image / streamed dataflow sweep,
+the W-step normal equations and their fp64 Cholesky, als_item_stats on the 66 KB LDS image) and at FULL size
+on one GPU (~170 GB of HBM; skipped only when the device has less free memory than that).
+
 Inputs are bench.py's synthetic generators (the same bytes the headline number is measured on)."""
 import numpy as np
 import pytest
@@ -199,3 +205,168 @@ def test_cfg3_full_size_w_step_is_the_ridge_optimum():
     f_, a_ = fused.cpu().numpy(), alone.cpu().numpy()
     assert abs(f_[0] - a_[0]) / nnz < 2e-6
     assert abs(np.sqrt(f_[1] / nnz) - np.sqrt(a_[1] / nnz)) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: the full model at k = 128
+# ------------------------------------------------------------------------------------------------------
+def _sample_by_length(lens, rng, classes, extra=()):
+    picks = list(extra)
+    for lo_len, hi_len in classes:
+        cand = np.nonzero((lens >= lo_len) & (lens <= hi_len))[0]
+        if cand.size:
+            picks += list(rng.choice(cand, size=min(8, cand.size), replace=False))
+    return np.unique(np.array(picks, dtype=np.int64))
+
+
+def _full_model_properties(size, resid_tol=2e-6):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected (-m gpu) but no ROCm device is visible")
+    import bench
+    from collaborative_filtering_amd import ALS, ALSConfig, BiasesConfig, CoreConfig, GraphConfig, GraphSimConfig
+    dev = torch.device("cuda", 0)
+    m, n, nnz, k = bench.SIZES[size]
+    features = bench.gen_features(n, 3004)
+    csr, csc = bench.gen_ratings(dev, m, n, nnz, seed=1004)
+    S = bench.gen_graph(dev, n, seed=2004)
+    lam_w = {"genres": 5.0, "years": 10.0}
+    cfg = ALSConfig(core=CoreConfig(n_factors=k, n_iters=3, lambda_u=5.0, lambda_v=6.0, random_state=42,
+                                    pop_reg_mode="inverse_sqrt"),
+                    biases=BiasesConfig(lambda_bu=3.0, lambda_bi=2.0),
+                    graph=GraphConfig(alpha=0.5, sim=GraphSimConfig(source="precomputed", topk=50)))
+    model = ALS(cfg, lambda_w=lam_w, device=dev)
+    eng = model.prepare_csr(csr, csc, (m, n), features=features, S=S)
+    assert eng.use_graph and eng.gs_dataflow and eng.fused_feat_stats and eng.ld == 128
+    eng.be.compose_z(eng.V, eng.Xcat, eng.Wcat, eng.Z)
+    eng.iteration(0, 3)                                   # one full iteration incl. a W-step: non-trivial state
+    torch.cuda.synchronize()
+    eng._check_status()
+    rng = np.random.default_rng(7)
+    mu = float(eng.mu.item())
+    f64 = torch.float64
+
+    # ---- U-step: every K1 row class (dual <= 64, dual-mid 65..96, primal, split > 4096) -----------------
+    b_u_old = eng.b_u.clone()
+    eng.user_step()
+    torch.cuda.synchronize()
+    eng._check_status()
+    uptr = eng.csr.indptr.cpu().numpy()
+    lens = np.diff(uptr)
+    assert eng.utasks.ndual > 0 and eng.utasks.nmid > 0          # both dual classes are exercised
+    users = _sample_by_length(lens, rng, ((1, 16), (17, 64), (65, 96), (97, 4096), (4097, 1 << 40)),
+                              extra=[int(lens.argmax()), int(lens.argmin())])
+    worst = 0.0
+    for u in users:
+        lo, hi = int(uptr[u]), int(uptr[u + 1])
+        cols = eng.csr.indices[lo:hi].long()
+        Zr = eng.Z[cols, :k].double().cpu().numpy()
+        r = eng.csr.vals[lo:hi].double().cpu().numpy()
+        bi = eng.b_i[cols].double().cpu().numpy()
+        rho = r - mu - float(b_u_old[u]) - bi
+        A = Zr.T @ Zr + (model.lambda_u + EPS) * np.eye(k)
+        x = eng.U[u, :k].double().cpu().numpy()
+        worst = max(worst, _rel_residual(A, x, Zr.T @ rho))
+        b_new = (r - mu - bi - Zr @ x).sum() / ((hi - lo) + model.lambda_bu + EPS)
+        assert abs(float(eng.b_u[u]) - b_new) < 2e-5, (u, hi - lo)
+    assert worst < resid_tol, worst
+
+    # ---- V-step (Gram + factor by-products) + Gauss-Seidel sweep with the live neighbour values --------
+    V_old, b_i_old = eng.V.clone(), eng.b_i.clone()
+    eng.b_i_prev = b_i_old
+    eng.item_step(want_gram=True)
+    torch.cuda.synchronize()
+    eng._check_status()
+    iptr = eng.csc.indptr.cpu().numpy()
+    ilen = np.diff(iptr)
+    sp = eng.S_ptr.cpu().numpy()
+    items = _sample_by_length(ilen, rng, ((1, 64), (65, 96), (97, 4096), (4097, 1 << 40)),
+                              extra=[0, n - 1, int(ilen.argmax()), int(ilen.argmin()), int(np.argmax(eng.sched.level))])
+    lam_row = eng.lam_v_row.cpu().numpy()
+    dex = eng.diag_extra.cpu().numpy()
+    worst = 0.0
+    for i in items:
+        lo, hi = int(iptr[i]), int(iptr[i + 1])
+        rows = eng.csc.indices[lo:hi].long()
+        Ur = eng.U[rows, :k].double().cpu().numpy()
+        r = eng.csc.vals[lo:hi].double().cpu().numpy()
+        bu = eng.b_u[rows].double().cpu().numpy()
+        rho = r - mu - bu - float(b_i_old[i])
+        nb = eng.S_idx[int(sp[i]):int(sp[i + 1])].long()
+        sv = eng.S_val[int(sp[i]):int(sp[i + 1])].double().cpu().numpy()
+        nb_h = nb.cpu().numpy()
+        live = np.where((nb_h < i)[:, None], eng.V[nb, :k].double().cpu().numpy(), V_old[nb, :k].double().cpu().numpy())
+        A = Ur.T @ Ur + (float(lam_row[i]) + EPS + float(dex[i])) * np.eye(k)
+        rhs = Ur.T @ rho + model.alpha * (sv @ live)
+        x = eng.V[i, :k].double().cpu().numpy()
+        worst = max(worst, _rel_residual(A, x, rhs))
+        b_new = (r - mu - bu - Ur @ x).sum() / ((hi - lo) + model.lambda_bi + EPS)
+        assert abs(float(eng.b_i[i]) - b_new) < 2e-5, (i, hi - lo)
+    assert worst < resid_tol, worst
+    del V_old
+
+    # ---- W-step: the projections zero the gradient of the reference's ridge problem (als.py:469-500) ----
+    W_old = {f: eng.W64[f].clone() for f in eng.feat_names}
+    eng.w_step(b_i_old)
+    torch.cuda.synchronize()
+    eng._check_status()
+    X = {f: torch.from_numpy(np.asarray(features[f], dtype=np.float64)).to(dev) for f in eng.feat_names}
+    XW_old = {f: X[f] @ W_old[f] for f in eng.feat_names}
+    XW_new = {f: X[f] @ eng.W64[f] for f in eng.feat_names}
+    T = {f: torch.zeros(n, k, dtype=f64, device=dev) for f in eng.feat_names}
+    Tb = {f: torch.zeros(n, k, dtype=f64, device=dev) for f in eng.feat_names}
+    uptr_d = eng.csr.indptr
+    step = max(1, min(m, (1 << 21) * m // max(nnz, 1)))     # users per chunk: ~2M ratings (2 GB per fp64 temporary)
+    for u0 in range(0, m, step):
+        u1 = min(u0 + step, m)
+        lo, hi = int(uptr_d[u0]), int(uptr_d[u1])
+        ru = torch.repeat_interleave(torch.arange(u0, u1, device=dev), uptr_d[u0 + 1:u1 + 1] - uptr_d[u0:u1])
+        ri = eng.csr.indices[lo:hi].long()
+        Uo = eng.U[ru, :k].to(f64)
+        base = (eng.csr.vals[lo:hi].to(f64) - mu - eng.b_u[ru].to(f64) - eng.b_i[ri].to(f64)
+                - (Uo * eng.V[ri, :k].to(f64)).sum(1))
+        own = {f: (Uo * XW_old[f][ri]).sum(1) for f in eng.feat_names}
+        for f in eng.feat_names:
+            base = base - own[f]                            # :475-479 (old W of every feature)
+        for f in eng.feat_names:
+            target = base + own[f]                          # :484-486
+            e = (Uo * XW_new[f][ri]).sum(1) - target
+            T[f].index_add_(0, ri, e[:, None] * Uo)
+            Tb[f].index_add_(0, ri, target[:, None] * Uo)
+        del ru, ri, Uo, base, own
+    for f in eng.feat_names:
+        grad = X[f].T @ T[f] + (lam_w[f] + EPS) * eng.W64[f]
+        rel = float(grad.norm() / (X[f].T @ Tb[f]).norm())
+        assert rel < 2e-5, (f, rel)
+        assert float((eng.W64[f] - W_old[f]).norm() / W_old[f].norm()) > 1e-4     # the step did move W
+
+    # ---- statistics with features: per-item closed form (als_item_stats) vs the pass over the ratings ----
+    eng.stats_step(1)
+    fused = eng.stats.clone()
+    alone = torch.zeros(2, dtype=f64, device=dev)
+    mu_before = eng.mu - fused[0] / nnz
+    eng.be.residual_stats(k=eng.k, ld=eng.ld, side=eng.csr, U=eng.U, Z=eng.Z, b_u=eng.b_u, b_i=eng.b_i,
+                          mu=mu_before, tasks=eng.utasks, out=alone)
+    f_, a_ = fused.cpu().numpy(), alone.cpu().numpy()
+    assert abs(f_[0] - a_[0]) / nnz < 2e-6
+    assert abs(np.sqrt(f_[1] / nnz) - np.sqrt(a_[1] / nnz)) < 2e-6
+    return eng
+
+
+def test_cfg5_small_full_model_properties():
+    """BASELINE configs[4] at shape / 50 (200K x 20K, 10M ratings, k = 128, full model)."""
+    _full_model_properties("cfg5-small")
+
+
+def test_cfg5_full_size_full_model_properties():
+    """BASELINE configs[4] at FULL size on one GPU: 10M users x 1M items, 1e9 ratings, k = 128, bias +
+    popularity-scaled lambda_v + genres / years projections + Laplacian (about 170 GB of the 288 GB HBM)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected (-m gpu) but no ROCm device is visible")
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 230e9:
+        pytest.skip(f"needs ~200 GB of free HBM, device has {free / 1e9:.0f} GB")
+    _full_model_properties("cfg5")
+    torch.cuda.empty_cache()
