@@ -289,7 +289,8 @@ def main():
                     graph=(GraphConfig(alpha=0.5, sim=GraphSimConfig(source="precomputed", topk=50))
                            if S is not None else GraphConfig()))
     model = ALS(cfg, lambda_w={"genres": 5.0, "years": 10.0} if features else None,
-                device=dev, gs_mode=args.gs_mode, gram=args.gram, hip_graph=args.hip_graph)
+                device=dev, gs_mode=args.gs_mode, gram=args.gram, hip_graph=args.hip_graph,
+                process_group="world" if dist_on else None)
     eng = model.prepare_csr(csr, csc, (m, n), features=features, S=S)
     if features:
         eng.be.compose_z(eng.V, eng.Xcat, eng.Wcat, eng.Z)

@@ -88,6 +88,18 @@ def _side_to_dev(s, device) -> _SideDev:
                     torch.from_numpy(s.vals).to(device))
 
 
+def _check_csr(indptr: torch.Tensor, indices: torch.Tensor, nrows: int, ncols: int, what: str):
+    """Structural validation of a caller-supplied CSR (one device reduction each): an index outside
+    [0, ncols) would be an out-of-bounds gather inside the kernels."""
+    if indptr.numel() != nrows + 1:
+        raise ValueError(f"{what}: indptr has {indptr.numel()} entries, expected {nrows + 1}")
+    nnz = indices.numel()
+    if int(indptr[0]) != 0 or int(indptr[-1]) != nnz or (nrows and bool((indptr[1:] < indptr[:-1]).any())):
+        raise ValueError(f"{what}: indptr must rise monotonically from 0 to nnz = {nnz}")
+    if nnz and (int(indices.min()) < 0 or int(indices.max()) >= ncols):
+        raise ValueError(f"{what}: index outside [0, {ncols})")
+
+
 def _as_side(triple, nrows: int, ncols: int):
     indptr, indices, vals = triple
     if isinstance(indptr, torch.Tensor):
@@ -95,10 +107,42 @@ def _as_side(triple, nrows: int, ncols: int):
             raise ValueError("device CSR needs int64 indptr, int32 indices, float32 vals")
         if indptr.numel() != nrows + 1 or indices.numel() != vals.numel():
             raise ValueError("inconsistent CSR sizes")
+        _check_csr(indptr, indices, nrows, ncols, "ratings CSR")
         return _SideDev(nrows, ncols, indptr.contiguous(), indices.contiguous(), vals.contiguous())
-    return layout.SparseSide(nrows, ncols, np.ascontiguousarray(indptr, dtype=np.int64),
-                             np.ascontiguousarray(indices, dtype=np.int32),
-                             np.ascontiguousarray(vals, dtype=np.float32))
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    _check_csr(torch.from_numpy(indptr), torch.from_numpy(indices), nrows, ncols, "ratings CSR")
+    return layout.SparseSide(nrows, ncols, indptr, indices, np.ascontiguousarray(vals, dtype=np.float32))
+
+
+def _validate_graph(ptr: torch.Tensor, idx: torch.Tensor, val: torch.Tensor, n: int):
+    """A caller-supplied similarity graph must be what the reference would have built (scripts/als.py:224-240):
+    indices inside [0, n), ascending inside every row, no diagonal, and SYMMETRIC in pattern and value
+    (S = max(S, S^T)).  The level schedule of the Gauss-Seidel sweep relies on the symmetry: a neighbour
+    j > i must sit on a later level so that it still holds its previous value when i is solved."""
+    _check_csr(ptr, idx, n, n, "similarity graph S")
+    if val.numel() != idx.numel():
+        raise ValueError("similarity graph S: values and indices differ in length")
+    if idx.numel() == 0:
+        return
+    rows = torch.repeat_interleave(torch.arange(n, device=ptr.device), ptr[1:] - ptr[:-1])
+    cols = idx.to(torch.int64)
+    key = rows * n + cols
+    if bool((key[1:] <= key[:-1]).any()):
+        raise ValueError("similarity graph S: column indices must be strictly ascending inside every row")
+    if bool((rows == cols).any()):
+        raise ValueError("similarity graph S: diagonal entries are not allowed (the reference zeroes them)")
+    tkey, order = torch.sort(cols * n + rows)
+    if not torch.equal(tkey, key) or not torch.equal(val[order], val):
+        raise ValueError("similarity graph S must be symmetric in pattern and value (S == S^T); "
+                         "symmetrise with max(S, S^T) as the reference does")
+
+
+def _on(device):
+    """Make `device` the current HIP device for the enclosed calls: the C-ABI library launches on the current
+    device (and sizes its persistent grids from that device's occupancy), torch only hands it a stream."""
+    import contextlib
+    return torch.cuda.device(device) if device.type == "cuda" else contextlib.nullcontext()
 
 
 def _to_dev(a, device, dtype) -> torch.Tensor:
@@ -154,6 +198,7 @@ class ALS:
             raise ValueError("graph_build must be 'host' (reference-identical, dense n x n) or 'device'")
         self._graph_build = graph_build
         self._hip_graph = bool(hip_graph)          # replay iterations as captured HIP graphs (one rank only)
+        self._validate_S = False
         self._eng: Optional[_Engine] = None
 
     # ------------------------------------------------------------------ fit
@@ -168,7 +213,12 @@ class ALS:
     def fit_coo(self, rows, cols, vals, shape, features: Optional[Dict[str, np.ndarray]] = None,
                 tol: Optional[float] = 1e-3, min_iters: int = 5, verbose: int = 1, *, S=None) -> "ALS":
         """Same as `fit` on COO triplets; nothing dense m x n is ever formed."""
-        csr, csc = layout.coo_to_sides(rows, cols, vals, (int(shape[0]), int(shape[1])))
+        shape = (int(shape[0]), int(shape[1]))
+        if self._backend is None:           # HIP backend: the set-up passes of the C-ABI library (host code)
+            from . import _hip
+            csr, csc = layout.coo_to_sides_native(_hip.load(), rows, cols, vals, shape)
+        else:
+            csr, csc = layout.coo_to_sides(rows, cols, vals, shape)
         return self._fit_sides(csr, csc, features, tol, min_iters, verbose, S)
 
     def fit_csr(self, csr, csc, shape, features: Optional[Dict[str, np.ndarray]] = None,
@@ -210,6 +260,7 @@ class ALS:
             if S is not None:
                 S_csr = tuple(S)
                 self.S = S_csr
+                self._validate_S = True
             else:
                 X = features.get(self.cfg.graph.sim.feature_name)
                 if X is None:                                # scripts/als.py:219-222
@@ -217,7 +268,8 @@ class ALS:
                                    "Graph regularization disabled.", self.cfg.graph.sim.feature_name)
                 elif self._graph_build == "device":
                     dev = self._device or torch.device("cuda", torch.cuda.current_device())
-                    S_csr = layout.build_similarity_device(X, self.S_topk, self.S_eps, dev)
+                    with _on(dev):
+                        S_csr = layout.build_similarity_device(X, self.S_topk, self.S_eps, dev)
                     self.S = S_csr[:3]
                 else:
                     self.S, S_csr = _similarity_cached(X, self.S_topk, self.S_eps)
@@ -228,7 +280,8 @@ class ALS:
         if backend is None:
             from .backend import HipBackend
             backend = HipBackend(device, gram=self._gram or "bf16x3")
-        self._eng = _Engine(self, csr, csc, features, S_csr, device, backend, self._pg, self._gs_mode)
+        with _on(device):
+            self._eng = _Engine(self, csr, csc, features, S_csr, device, backend, self._pg, self._gs_mode)
         if not run:                         # prepare(): the caller drives the iterations
             return self
         if verbose > 0:
@@ -237,8 +290,9 @@ class ALS:
                         "update_w_every=%s, world=%d", self.n_factors, self.n_iters, self.lambda_u,
                         self.lambda_v, self.pop_reg_mode, list(features), self.lambda_w,
                         self.random_state, self.alpha, self.update_w_every, self._eng.world)
-        self._eng.run(tol, min_iters, verbose)
-        self._eng.export(self)
+        with _on(device):
+            self._eng.run(tol, min_iters, verbose)
+            self._eng.export(self)
         if verbose > 0 and self.history["train_rmse"]:
             logger.info("ALS training finished. Final train RMSE: %.4f", self.history["train_rmse"][-1])
         return self
@@ -260,12 +314,14 @@ class ALS:
     def predict(self, features: Optional[Dict[str, np.ndarray]] = None) -> np.ndarray:
         """Completed matrix U Z^T + mu + b_u + b_i, (m, n) float64 (scripts/als.py:532-574)."""
         features = self._check_predict(features)
-        return self._eng.predict_dense(features)
+        with _on(self._eng.dev):
+            return self._eng.predict_dense(features)
 
     def predict_at(self, flat_idx, features: Optional[Dict[str, np.ndarray]] = None) -> np.ndarray:
         """Predictions at flat indices u*n+i (what scripts/tune_params.py:165-166 reads)."""
         features = self._check_predict(features)
-        return self._eng.predict_at(np.asarray(flat_idx, dtype=np.int64), features)
+        with _on(self._eng.dev):
+            return self._eng.predict_at(np.asarray(flat_idx, dtype=np.int64), features)
 
 
 class _Engine:
@@ -277,14 +333,27 @@ class _Engine:
         self.model = model
         self.dev = device
         self.be = backend
-        self.pg = pg
-        if pg is not None or (dist.is_available() and dist.is_initialized()):
+        # sharding is opt-in: process_group="world" (the default group) or a ProcessGroup object; None fits on
+        # this rank alone even when torch.distributed happens to be initialised
+        if isinstance(pg, str):
+            if pg != "world":
+                raise ValueError("process_group must be None, 'world' or a torch.distributed ProcessGroup")
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("process_group='world' needs an initialised torch.distributed")
+            self.pg, self.dist_on = None, True
+        else:
+            self.pg, self.dist_on = pg, pg is not None
+        pg = self.pg
+        if self.dist_on:
             self.world, self.rank = dist.get_world_size(pg), dist.get_rank(pg)
         else:
             self.world, self.rank = 1, 0
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                logger.info("torch.distributed is initialised (world %d) but no process_group was given: "
+                            "fitting on this rank alone", dist.get_world_size())
         # `multi`: take the sharded code path with its collectives.  ALS_FORCE_COLLECTIVES=1 takes it on a
         # one-rank group too, to rehearse the RCCL calls on a single GPU (bench.py / tests only).
-        self.multi = self.world > 1 or (os.environ.get("ALS_FORCE_COLLECTIVES") == "1" and dist.is_initialized())
+        self.multi = self.world > 1 or (os.environ.get("ALS_FORCE_COLLECTIVES") == "1" and self.dist_on)
         k = int(model.n_factors)
         self.k, self.ld = k, layout.padded_k(k)
         self.m, self.n = csr.nrows, csc.nrows
@@ -310,13 +379,20 @@ class _Engine:
         iptr_h = self.csc.indptr.cpu().numpy()
         dl = layout.dual_max_len(k)          # rows this short are solved in the dual form (k_row_dual)
         dm = layout.dual_mid_len(k)          # ... and rows up to this length above k = 96 (k_row_dual_mid)
-        self.utasks = _tasks_to_dev(layout.build_row_tasks(uptr_h, self.ub, self.ue, dual_len=dl, mid_len=dm), device)
-        self.itasks = _tasks_to_dev(layout.build_row_tasks(iptr_h, self.ib, self.ie, dual_len=dl, mid_len=dm), device)
+        lib = getattr(backend, "lib", None)  # HIP backend: set-up passes in the library (csrc/host_setup.cpp)
+
+        def row_tasks(ptr, lo, hi):
+            if lib is not None:
+                return layout.build_row_tasks_native(lib, ptr, lo, hi, dual_len=dl, mid_len=dm)
+            return layout.build_row_tasks(ptr, lo, hi, dual_len=dl, mid_len=dm)
+
+        self.utasks = _tasks_to_dev(row_tasks(uptr_h, self.ub, self.ue), device)
+        self.itasks = _tasks_to_dev(row_tasks(iptr_h, self.ib, self.ie), device)
         if self.u_chunks > 1:
             sub = self.u_per // self.u_chunks
             lo0 = self.rank * self.u_per
-            self.utasks_c = [_tasks_to_dev(layout.build_row_tasks(uptr_h, min(lo0 + c * sub, self.m),
-                                                                  min(lo0 + (c + 1) * sub, self.m), dual_len=dl, mid_len=dm),
+            self.utasks_c = [_tasks_to_dev(row_tasks(uptr_h, min(lo0 + c * sub, self.m),
+                                                     min(lo0 + (c + 1) * sub, self.m)),
                                            device)
                              for c in range(self.u_chunks)]
             self.u_stage = torch.empty(self.u_chunks, self.world, sub, self.ld, dtype=torch.float32, device=device)
@@ -371,6 +447,10 @@ class _Engine:
             self.S_ptr = _to_dev(S_csr[0], device, torch.int64)
             self.S_idx = _to_dev(S_csr[1], device, torch.int32)
             self.S_val = _to_dev(S_csr[2], device, f32)
+            if model._validate_S:                 # caller-supplied graph: checked once, on the device
+                if self.S_ptr.numel() != self.n + 1:
+                    raise ValueError(f"similarity graph S has {self.S_ptr.numel() - 1} rows; expected {self.n}")
+                _validate_graph(self.S_ptr, self.S_idx, self.S_val, self.n)
             ptr = self.S_ptr.cpu().numpy()
             idx = self.S_idx.cpu().numpy()
             if len(S_csr) > 3:
@@ -394,19 +474,22 @@ class _Engine:
             if self.gs_mode not in ("exact", "block", "levels"):
                 raise ValueError(f"unknown gs_mode '{self.gs_mode}'")
             active = counts > 0
-            if self.multi and self.gs_mode == "levels":
-                sched = layout.build_level_schedule(ptr, idx, active, 0, self.n)
-            else:
-                sched = layout.build_level_schedule(ptr, idx, active, self.ib, self.ie)
-            self.sched = sched
-            self.sched_items = torch.from_numpy(sched.items).to(device)
             # persistent dataflow sweep (one launch, no level barriers) when the backend has it
             self.gs_dataflow = (hasattr(backend, "gs_dataflow")
                                 and not (self.multi and self.gs_mode == "levels"))
+            lo, hi = (0, self.n) if (self.multi and self.gs_mode == "levels") else (self.ib, self.ie)
+            if lib is not None:
+                sched, wait = layout.build_level_schedule_native(lib, ptr, idx, active, lo, hi,
+                                                                 want_wait=self.gs_dataflow)
+            else:
+                sched = layout.build_level_schedule(ptr, idx, active, lo, hi)
+                wait = layout.wait_edges(ptr, idx, sched.level) if self.gs_dataflow else None
+            self.sched = sched
+            self.sched_items = torch.from_numpy(sched.items).to(device)
             if self.gs_dataflow:
-                self.S_idx_wait = torch.from_numpy(layout.wait_edges(ptr, idx, sched.level)).to(device)
+                self.S_idx_wait = torch.from_numpy(wait).to(device)
                 self.gs_publish = torch.empty(n_pad, self.ld, dtype=f32, device=device)       # same shape as V
-                self.gs_err = torch.zeros(1, dtype=torch.int32, device=device)
+                self.gs_err = torch.zeros(2, dtype=torch.int32, device=device)    # [error flag, work counter]
             self.factor = torch.zeros(n_pad * self.ld * self.ld, dtype=f32, device=device)
             self.sumr = torch.zeros(n_pad, dtype=f32, device=device)
         need_byproducts = self.use_graph or bool(self.feat_names)
@@ -470,7 +553,7 @@ class _Engine:
     def _check_status(self):
         if getattr(self, "w_bad", None) is not None and int(self.w_bad.item()):
             raise np.linalg.LinAlgError("W-step normal equations of a feature are not positive definite")
-        if getattr(self, "gs_dataflow", False) and int(self.gs_err.item()):
+        if getattr(self, "gs_dataflow", False) and int(self.gs_err[0].item()):
             raise RuntimeError("Gauss-Seidel dataflow sweep: a dependency wait timed out")
         bad = int(self.status.item())
         if bad:
@@ -645,8 +728,6 @@ class _Engine:
         w_step.hip (als_w_normal_equations) in fp64 and are solved by the blocked
         fp64 Cholesky of spd_solve.hip (als_spd_solve_f64).
         """
-        if not hasattr(self.be, "w_accumulate"):
-            return self._w_step_host_algebra(b_i_old)        # test stand-in backends only
         md = self.model
         k, ld = self.k, self.ld
         if not hasattr(self, "H"):
@@ -670,54 +751,6 @@ class _Engine:
             x = self.be.spd_solve(A_full, B_full, float(md.lambda_w.get(f, 0.0)) + EPS, self.w_status)
             torch.maximum(self.w_bad, self.w_status, out=self.w_bad)     # no host round trip inside an iteration
             newW[f] = x.reshape(d, k)
-        self.W64.update(newW)
-        self._sync_wcat()
-
-    def _w_step_host_algebra(self, b_i_old: torch.Tensor):
-        """Same normal equations with torch tensor algebra (fp64).  Used only when the backend has no
-        W kernels, i.e. by the numpy stand-in of the CPU tests; the HIP backend never takes this path."""
-        md = self.model
-        k, ld = self.k, self.ld
-        f64 = torch.float64
-        sl = slice(self.ib, self.ie)
-        # perm-space -> storage order, real columns only
-        pos = self.perm[:ld]                       # pos[c] = perm position of storage col c
-        pk = pos[:k]
-        Graw = self.gram[sl]                       # [nl, ld, ld] perm space, lower blocks valid
-        blk = torch.arange(ld, device=self.dev) // 16
-        lo = (blk[:, None] >= blk[None, :])
-        slo = (blk[:, None] > blk[None, :])
-        Glo = torch.where(lo, Graw, torch.zeros((), dtype=Graw.dtype, device=self.dev))
-        Gfull = Glo + torch.where(slo, Graw, torch.zeros((), dtype=Graw.dtype, device=self.dev)).transpose(1, 2)
-        G = Gfull[:, pk][:, :, pk].to(f64)         # [nl, k, k] storage order
-        rhs = self.rhs_out[sl][:, pk].to(f64)      # U_i^T r_i with the old b_i
-        cs = self.colsum_out[sl][:, pk].to(f64)
-        db = (self.b_i[sl].to(f64) - b_i_old[sl].to(f64))[:, None]
-        Ut_rho = rhs - db * cs
-        V64 = self.V[sl, :k].to(f64)
-        xw = {f: self.X64[f][sl] @ self.W64[f] for f in self.feat_names}     # old W
-        z = V64.clone()
-        for f in self.feat_names:
-            z += xw[f]
-        g = Ut_rho - torch.bmm(G, z.unsqueeze(2)).squeeze(2)
-        newW = {}
-        Gflat = G.reshape(G.shape[0], k * k)
-        for f, d in zip(self.feat_names, self.feat_dims):
-            X = self.X64[f][sl]
-            h = g + torch.bmm(G, xw[f].unsqueeze(2)).squeeze(2)
-            B = X.transpose(0, 1) @ h                                      # [d, k]
-            Pm = (X[:, :, None] * X[:, None, :]).reshape(X.shape[0], d * d)
-            T = Pm.transpose(0, 1) @ Gflat                                  # [d*d, k*k]
-            A = T.reshape(d, d, k, k).permute(0, 2, 1, 3).reshape(d * k, d * k).contiguous()
-            if self.multi:
-                self._allreduce(A)
-                self._allreduce(B)
-            lam = float(md.lambda_w.get(f, 0.0))
-            A.diagonal().add_(lam + EPS)
-            L, info = torch.linalg.cholesky_ex(A)
-            if int(info.item()) != 0:
-                raise np.linalg.LinAlgError(f"W-step normal equations of feature '{f}' are not positive definite")
-            newW[f] = torch.cholesky_solve(B.reshape(d * k, 1), L).reshape(d, k)
         self.W64.update(newW)
         self._sync_wcat()
 
@@ -754,6 +787,9 @@ class _Engine:
     def iteration(self, it: int, n_iters: int):
         """One full ALS iteration (scripts/als.py:408-517), asynchronous on the stream."""
         md = self.model
+        if self.dev.type == "cuda" and torch.cuda.current_device() != self.dev.index and self.dev.index is not None:
+            with torch.cuda.device(self.dev):          # callers that drive iterations themselves (bench.py)
+                return self.iteration(it, n_iters)
         do_w = bool(self.feat_names) and ((it % md.update_w_every == 0) or (it == n_iters - 1))   # :468
         if self.model._hip_graph and not self.multi and self.timers is None and it > 0:
             self._replay(do_w)

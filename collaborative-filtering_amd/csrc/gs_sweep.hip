@@ -8,6 +8,7 @@
 // Items of one level ("Level schedule") do not neighbour each
 // other, so one launch solves a whole level with one wavefront per item:
 //   b = rhs_i + alpha * sum_j S_ij V_j ;  V_i = (L L^T)^{-1} b ;  bias update.
+#include <atomic>
 #include <cstdlib>
 #include "als_device.hpp"
 #include "als_hip.h"
@@ -153,10 +154,15 @@ void k_gs_level(const als_gs_sweep_params P) {
 // ---------------------------------------------------------------------------
 // K2': the whole sweep as ONE persistent, synchronisation-free launch.
 //
-// Items are listed in (level, id) order and dealt round-robin to `nwaves` co-resident waves; each wave
-// walks its items in that order.  An item waits only for the neighbours it really depends on (j < i and
-// swept - flagged by the sign bit of `Sw`); there is no level barrier.  Progress: the earliest unfinished
-// item in the global order has all dependencies finished and is the next item of a resident wave.
+// Items are listed in (level, id) order and handed out through a ticket counter: a wave draws the next
+// position of that list with one atomic (the following ticket is drawn before the current item is worked on,
+// so the round trip is hidden).  An item waits only for the neighbours it really depends on (j < i and swept -
+// flagged by the sign bit of `Sw`); there is no level barrier.  Progress needs NO co-residency of the grid:
+// an item is only ever held by a wave that is running, tickets rise inside a wave, so the earliest unfinished
+// item of the global order is some running wave's current item and all its dependencies (earlier items) are
+// finished.  Workgroups that start late - another kernel or process occupying CUs - simply find higher
+// tickets (a static round-robin deal would leave their items unowned while the resident waves spin on them).
+// Which wave solves an item has no influence on the result.
 //
 // Hand-off: solved rows travel through the publication buffer `pub` (same shape as V), every word of which
 // the launcher resets to GS_SENTINEL.  A producer stores its row there with agent-scope (sc1, write-
@@ -194,7 +200,7 @@ struct DfCfg {
 template <int KB, bool STREAM>
 __global__ __launch_bounds__((64 * DfCfg<KB, STREAM>::WPW), (DfCfg<KB, STREAM>::IMAGE ? 1 : 2))
 void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, float* pub,
-                   int32_t* err, int64_t nitems, int nwaves) {
+                   int32_t* err, int64_t nitems) {
     using C = KCfg<KB>;
     constexpr int KP = C::KP, NR = C::NR;
     using D = DfCfg<KB, STREAM>;
@@ -206,14 +212,23 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
     float* vec = lds_img + (IMAGE ? KP * LD : 0);
     float* dinv = vec + (IMAGE ? 2 * KP : 0);
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * D::WPW + (threadIdx.x >> 6);
     int ic[NR], col[NR];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
         ic[rr] = min(lane + 64 * rr, KP - 1);
         col[rr] = perm_to_col<KB>(ic[rr]);
     }
-    for (int64_t it = gw; it < nitems; it += nwaves) {
+    int32_t* ticket = err + 1;                       // zeroed by the launcher
+    auto draw = [&]() -> int {
+        int t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return t;                                    // lane 0 holds the ticket; read with readfirstlane when needed
+    };
+    int t_next = draw();
+    for (;;) {
+        const int64_t it = __builtin_amdgcn_readfirstlane(t_next);
+        if (it >= nitems) break;
+        t_next = draw();                             // in flight underneath this item's work
         const int item = P.items[it];
         const int64_t i64 = item;
         const int64_t s0 = P.S_ptr[item], s1 = P.S_ptr[item + 1];
@@ -431,24 +446,31 @@ int launch_gs_dataflow_as(const als_gs_sweep_params* p, const int32_t* Sw, float
     // resident ones wait for its items): the grid is sized from the occupancy the runtime reports for this
     // kernel - registers and LDS included - times the number of CUs, capped at 8 waves per CU.
     constexpr int WPW = DfCfg<KB, STREAM>::WPW;
-    static int per_cu = 0, ncu = 0;
-    if (per_cu == 0) {
-        int dev = 0, nb = 0;
+    constexpr int MAXDEV = 64;
+    static std::atomic<int> per_cu_of[MAXDEV], ncu_of[MAXDEV];      // per device; zero-initialised; benign races
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return ALS_E_LAUNCH;
+    int per_cu = per_cu_of[dev].load(std::memory_order_relaxed), ncu = ncu_of[dev].load(std::memory_order_relaxed);
+    if (per_cu == 0 || ncu == 0) {
+        int nb = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gs_dataflow<KB, STREAM>, 64 * WPW, 0) != hipSuccess ||
             nb < 1)
             return ALS_E_LAUNCH;
         ncu = prop.multiProcessorCount;
         per_cu = nb * WPW > 8 ? 8 / WPW : nb;
         if (per_cu < 1) per_cu = 1;
+        ncu_of[dev].store(ncu, std::memory_order_relaxed);
+        per_cu_of[dev].store(per_cu, std::memory_order_relaxed);
     }
     if (waves_out) { *waves_out = ncu * per_cu * WPW; return 0; }
+    // the grid fills the device once (more workgroups would only queue up behind the resident ones); the ticket
+    // counter makes the sweep correct for ANY number of resident workgroups
     int nwg = ncu * per_cu;
     if ((int64_t)nwg * WPW > nitems) nwg = (int)((nitems + WPW - 1) / WPW);
     if (nwg < 1) return 0;
-    hipLaunchKernelGGL((k_gs_dataflow<KB, STREAM>), dim3(nwg), dim3(64 * WPW), 0, st, *p, Sw, pub, err, nitems,
-                       nwg * WPW);
+    hipLaunchKernelGGL((k_gs_dataflow<KB, STREAM>), dim3(nwg), dim3(64 * WPW), 0, st, *p, Sw, pub, err, nitems);
     return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
 }
 
@@ -489,7 +511,8 @@ extern "C" int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t
     if (p->stat_out && (!p->sumr2 || !p->lambda_eff)) return ALS_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (p->nitems > 0 && nrows > 0 &&
-        hipMemsetD32Async((hipDeviceptr_t)publish, (int)GS_SENTINEL, (size_t)nrows * ld, st) != hipSuccess)
+        (hipMemsetD32Async((hipDeviceptr_t)publish, (int)GS_SENTINEL, (size_t)nrows * ld, st) != hipSuccess ||
+         hipMemsetD32Async((hipDeviceptr_t)(err + 1), 0, 1, st) != hipSuccess))          // ticket counter
         return ALS_E_LAUNCH;
     switch (ld / 16) {
         case 1: return launch_gs_dataflow<1>(p, S_idx_wait, publish, err, p->nitems, st);

@@ -1,0 +1,175 @@
+// Host-side set-up of the HBM-resident structures, O(nnz) and off the Python interpreter.
+//
+// The reference builds its per-user / per-item index lists once per fit (scripts/als.py:332-340) and its
+// callers time fit + predict together (scripts/evaluate_models.py:245-255), so set-up is inside the measured
+// region of the named caller.  These entry points restate collaborative-filtering_amd/layout.py's numpy
+// definitions (kept there as the executable specification the tests compare against) as single passes:
+//   als_host_coo_to_sides     COO ratings -> CSR by user + CSC by item (three stable counting sorts)
+//   als_host_row_tasks        task list of als_row_solve: split rows > ALS_SPLIT_CHUNK, longest first,
+//                             dual-form classes last
+//   als_host_level_schedule   dependency levels of the index-ordered Gauss-Seidel sweep, the (level, id)
+//                             item order, and the wait flags of als_gs_sweep_dataflow
+// All pointers are HOST pointers.  Plain C++, no device code.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "als_hip.h"
+
+extern "C" int als_host_coo_to_sides(int64_t m, int64_t n, int64_t N, const int64_t* rows, const int64_t* cols,
+                                     const float* vals, int64_t* uptr, int32_t* uidx, float* uval,
+                                     int64_t* iptr, int32_t* iidx, float* ival) {
+    if (m < 0 || n < 0 || N < 0 || m >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 31)) return ALS_E_BADARG;
+    if (N > 0 && (!rows || !cols || !vals)) return ALS_E_BADARG;
+    if (!uptr || !iptr || (N > 0 && (!uidx || !uval || !iidx || !ival))) return ALS_E_BADARG;
+    std::fill(uptr, uptr + m + 1, (int64_t)0);
+    std::fill(iptr, iptr + n + 1, (int64_t)0);
+    for (int64_t t = 0; t < N; ++t) {
+        const int64_t r = rows[t], c = cols[t];
+        if (r < 0 || r >= m || c < 0 || c >= n) return -10;              // index outside the matrix shape
+        ++uptr[r + 1];
+        ++iptr[c + 1];
+    }
+    for (int64_t r = 0; r < m; ++r) uptr[r + 1] += uptr[r];
+    for (int64_t c = 0; c < n; ++c) iptr[c + 1] += iptr[c];
+    // row-major input (what np.nonzero of the dense matrix yields) needs one pass; anything else goes through
+    // a stable sort by column first so that the stable sort by row leaves the columns ascending inside a row
+    bool sorted = true;
+    for (int64_t t = 1; t < N && sorted; ++t)
+        sorted = rows[t] > rows[t - 1] || (rows[t] == rows[t - 1] && cols[t] > cols[t - 1]);
+    std::vector<int64_t> pos(std::max(m, n) + 1);
+    if (sorted) {
+        for (int64_t t = 0; t < N; ++t) { uidx[t] = (int32_t)cols[t]; uval[t] = vals[t]; }
+    } else {
+        std::vector<int64_t> by_col(N);
+        std::copy(iptr, iptr + n, pos.begin());
+        for (int64_t t = 0; t < N; ++t) by_col[pos[cols[t]]++] = t;
+        std::copy(uptr, uptr + m, pos.begin());
+        for (int64_t s = 0; s < N; ++s) {
+            const int64_t t = by_col[s];
+            const int64_t d = pos[rows[t]]++;
+            uidx[d] = (int32_t)cols[t];
+            uval[d] = vals[t];
+        }
+        for (int64_t r = 0; r < m; ++r)
+            for (int64_t e = uptr[r] + 1; e < uptr[r + 1]; ++e)
+                if (uidx[e] == uidx[e - 1]) return -11;                   // duplicate (user, item) entry
+    }
+    // CSC: stable pass over the CSR entries by column -> users ascending inside every column
+    std::copy(iptr, iptr + n, pos.begin());
+    for (int64_t r = 0; r < m; ++r)
+        for (int64_t e = uptr[r]; e < uptr[r + 1]; ++e) {
+            const int64_t d = pos[uidx[e]]++;
+            iidx[d] = (int32_t)r;
+            ival[d] = uval[e];
+        }
+    return 0;
+}
+
+// counts[6] = {ntasks, nlong, nslots, nnz, ndual, nmid}; tasks / long_rows may be NULL to query the counts.
+extern "C" int als_host_row_tasks(const int64_t* indptr, int64_t row_begin, int64_t row_end, int32_t chunk,
+                                  int32_t dual_len, int32_t mid_len, als_task* tasks, als_long_row* long_rows,
+                                  int64_t* counts) {
+    if (!indptr || !counts || row_begin < 0 || row_end < row_begin || chunk < 1) return ALS_E_BADARG;
+    int64_t ntasks = 0, nlong = 0, nslots = 0, nnz = 0, ndual = 0, nmid = 0;
+    // bucket sizes by segment length (1 .. chunk), three classes: 0 = everything else, 1 = mid, 2 = dual tail
+    std::vector<int64_t> bucket(3 * ((size_t)chunk + 1), 0);
+    auto cls_of = [&](int64_t len, bool whole) { return whole && len <= dual_len ? 2 : (whole && len <= mid_len ? 1 : 0); };
+    for (int64_t r = row_begin; r < row_end; ++r) {
+        const int64_t c = indptr[r + 1] - indptr[r];
+        if (c <= 0) continue;
+        nnz += c;
+        const int64_t nseg = (c + chunk - 1) / chunk;
+        if (nseg > 1) {
+            ++nlong;
+            nslots += nseg;
+            ntasks += nseg;
+            bucket[(size_t)chunk] += nseg - 1;
+            bucket[(size_t)(c - (nseg - 1) * chunk)] += 1;
+        } else {
+            ++ntasks;
+            const int cls = cls_of(c, true);
+            bucket[(size_t)cls * (chunk + 1) + c] += 1;
+            ndual += cls == 2;
+            nmid += cls == 1;
+        }
+    }
+    counts[0] = ntasks; counts[1] = nlong; counts[2] = nslots; counts[3] = nnz; counts[4] = ndual; counts[5] = nmid;
+    if (!tasks) return 0;
+    if (nlong > 0 && !long_rows) return ALS_E_BADARG;
+    // longest first inside a class, classes in the order 0, 1, 2; equal lengths keep the order of layout.py
+    // (segments of split rows in row order first, then the whole rows in row order)
+    std::vector<int64_t> start(bucket.size());
+    int64_t acc = 0;
+    for (int cls = 0; cls < 3; ++cls)
+        for (int64_t len = chunk; len >= 0; --len) {
+            start[(size_t)cls * (chunk + 1) + len] = acc;
+            acc += bucket[(size_t)cls * (chunk + 1) + len];
+        }
+    int64_t slot = 0, li = 0;
+    for (int64_t r = row_begin; r < row_end; ++r) {              // segments of split rows
+        const int64_t c = indptr[r + 1] - indptr[r];
+        const int64_t nseg = c > 0 ? (c + chunk - 1) / chunk : 0;
+        if (nseg <= 1) continue;
+        long_rows[li++] = als_long_row{(int32_t)r, (int32_t)slot, (int32_t)nseg, 0};
+        for (int64_t s = 0; s < nseg; ++s) {
+            const int64_t len = std::min<int64_t>(chunk, c - s * chunk);
+            tasks[start[(size_t)len]++] = als_task{(int32_t)r, (int32_t)s, (int32_t)(slot + s), 0};
+        }
+        slot += nseg;
+    }
+    for (int64_t r = row_begin; r < row_end; ++r) {              // whole rows
+        const int64_t c = indptr[r + 1] - indptr[r];
+        if (c <= 0 || c > chunk) continue;
+        const int cls = cls_of(c, true);
+        tasks[start[(size_t)cls * (chunk + 1) + c]++] = als_task{(int32_t)r, 0, -1, 0};
+    }
+    return 0;
+}
+
+// level[n] (-1 = not swept), items[<= n] in (level, id) order, offsets[nlevels + 1] (caller provides n + 1
+// entries), wait (nullable) = S_idx with the sign bit on the edges (i -> j), j < i, both swept.
+// out[2] = {nitems, nlevels}.
+extern "C" int als_host_level_schedule(int64_t n, const int64_t* S_ptr, const int32_t* S_idx, const uint8_t* active,
+                                       int64_t begin, int64_t end, int64_t* level, int32_t* items,
+                                       int64_t* offsets, int32_t* wait, int64_t* out) {
+    if (n < 0 || !S_ptr || !active || !level || !items || !offsets || !out || begin < 0 || end > n || begin > end ||
+        (S_ptr[n] > 0 && !S_idx))
+        return ALS_E_BADARG;
+    std::fill(level, level + n, (int64_t)-1);
+    int64_t nitems = 0, maxlev = -1;
+    for (int64_t i = begin; i < end; ++i) {
+        if (!active[i]) continue;
+        int64_t lv = -1;
+        for (int64_t e = S_ptr[i]; e < S_ptr[i + 1]; ++e) {
+            const int64_t j = S_idx[e];
+            if (j < i && j >= begin) lv = std::max(lv, level[j]);         // inactive neighbours carry -1
+        }
+        level[i] = lv + 1;
+        maxlev = std::max(maxlev, lv + 1);
+        ++nitems;
+    }
+    const int64_t nlev = maxlev + 1;
+    std::fill(offsets, offsets + nlev + 1, (int64_t)0);
+    for (int64_t i = begin; i < end; ++i)
+        if (level[i] >= 0) ++offsets[level[i] + 1];
+    for (int64_t l = 0; l < nlev; ++l) offsets[l + 1] += offsets[l];
+    {
+        std::vector<int64_t> pos(offsets, offsets + nlev);
+        for (int64_t i = begin; i < end; ++i)
+            if (level[i] >= 0) items[pos[level[i]]++] = (int32_t)i;
+    }
+    if (wait) {
+        for (int64_t i = 0; i < n; ++i) {
+            const bool swept = level[i] >= 0;
+            for (int64_t e = S_ptr[i]; e < S_ptr[i + 1]; ++e) {
+                const int32_t j = S_idx[e];
+                wait[e] = (swept && j < i && level[j] >= 0) ? (int32_t)(j | INT32_MIN) : j;
+            }
+        }
+    }
+    out[0] = nitems;
+    out[1] = nlev;
+    return 0;
+}

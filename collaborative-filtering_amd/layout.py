@@ -1,10 +1,17 @@
-"""Host-side (numpy) preparation of the HBM-resident data structures.
+"""Host-side preparation of the HBM-resident data structures.
 
 Everything here runs once per `fit`, before the timed loop: COO -> CSR/CSC,
 the row-task lists consumed by `als_row_solve` (include/als_hip.h), the
 perm-space index map, and the Gauss-Seidel level schedule of the Laplacian
 sweep.  It restates the reference's adjacency construction
 (scripts/als.py:332-340) on sparse input; nothing is dense m x n.
+
+The numpy functions are the executable specification; the `*_native`
+variants run the same passes in the C-ABI library (csrc/host_setup.cpp,
+single O(nnz) loops off the interpreter) and are what the engine uses with
+the HIP backend - the reference's caller times fit + predict together, so
+set-up is inside its measured region.  tests/test_layout_properties.py holds
+the two to identical outputs.
 """
 from __future__ import annotations
 
@@ -284,3 +291,68 @@ def build_level_schedule(S_ptr: np.ndarray, S_idx: np.ndarray, active: np.ndarra
     if swept.size:
         np.cumsum(np.bincount(level[swept], minlength=nlev), out=offsets[1:])
     return LevelSchedule(items, offsets, level)
+
+
+# --------------------------------------------------------------------------------------------------------
+# native (C-ABI, host) forms of the set-up passes: same outputs as the numpy definitions above
+# --------------------------------------------------------------------------------------------------------
+def _vp(a: np.ndarray):
+    import ctypes as C
+    return C.c_void_p(a.ctypes.data)
+
+
+def coo_to_sides_native(lib, rows, cols, vals, shape) -> Tuple[SparseSide, SparseSide]:
+    m, n = int(shape[0]), int(shape[1])
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    cols = np.ascontiguousarray(cols, dtype=np.int64)
+    vals = np.ascontiguousarray(vals, dtype=np.float32)
+    N = rows.size
+    uptr, iptr = np.empty(m + 1, np.int64), np.empty(n + 1, np.int64)
+    uidx, iidx = np.empty(N, np.int32), np.empty(N, np.int32)
+    uval, ival = np.empty(N, np.float32), np.empty(N, np.float32)
+    rc = lib.als_host_coo_to_sides(m, n, N, _vp(rows), _vp(cols), _vp(vals), _vp(uptr), _vp(uidx), _vp(uval),
+                                   _vp(iptr), _vp(iidx), _vp(ival))
+    if rc == -10:
+        raise ValueError("rating index outside the matrix shape")
+    if rc == -11:
+        raise ValueError("duplicate (user, item) entries")
+    if rc != 0:
+        raise RuntimeError(f"als_host_coo_to_sides failed with status {rc}")
+    return SparseSide(m, n, uptr, uidx, uval), SparseSide(n, m, iptr, iidx, ival)
+
+
+def build_row_tasks_native(lib, indptr: np.ndarray, row_begin: int = 0, row_end: Optional[int] = None,
+                           chunk: int = SPLIT_CHUNK, dual_len: int = DUAL_MAX_LEN, mid_len: int = 0) -> RowTasks:
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    row_end = len(indptr) - 1 if row_end is None else row_end
+    counts = np.zeros(6, np.int64)
+    args = (_vp(indptr), int(row_begin), int(row_end), int(chunk), int(dual_len), int(mid_len))
+    rc = lib.als_host_row_tasks(*args, None, None, _vp(counts))
+    if rc != 0:
+        raise RuntimeError(f"als_host_row_tasks failed with status {rc}")
+    tasks = np.zeros((int(counts[0]), 4), np.int32)
+    long_rows = np.zeros((int(counts[1]), 4), np.int32)
+    rc = lib.als_host_row_tasks(*args, _vp(tasks), _vp(long_rows), _vp(counts))
+    if rc != 0:
+        raise RuntimeError(f"als_host_row_tasks failed with status {rc}")
+    return RowTasks(tasks, long_rows, int(counts[2]), int(counts[3]), int(counts[4]), int(counts[5]))
+
+
+def build_level_schedule_native(lib, S_ptr: np.ndarray, S_idx: np.ndarray, active: np.ndarray, begin: int = 0,
+                                end: Optional[int] = None, want_wait: bool = True):
+    """(LevelSchedule, S_idx_wait or None) - `build_level_schedule` and `wait_edges` in one pass."""
+    S_ptr = np.ascontiguousarray(S_ptr, dtype=np.int64)
+    S_idx = np.ascontiguousarray(S_idx, dtype=np.int32)
+    act = np.ascontiguousarray(active, dtype=np.uint8)
+    n = len(S_ptr) - 1
+    end = n if end is None else end
+    level = np.empty(n, np.int64)
+    items = np.empty(n, np.int32)
+    offsets = np.empty(n + 1, np.int64)
+    wait = np.empty(S_idx.size, np.int32) if want_wait else None
+    out = np.zeros(2, np.int64)
+    rc = lib.als_host_level_schedule(n, _vp(S_ptr), _vp(S_idx), _vp(act), int(begin), int(end), _vp(level),
+                                     _vp(items), _vp(offsets), _vp(wait) if want_wait else None, _vp(out))
+    if rc != 0:
+        raise RuntimeError(f"als_host_level_schedule failed with status {rc}")
+    return LevelSchedule(items[: int(out[0])].copy(), offsets[: int(out[1]) + 1].copy(), level), wait

@@ -191,8 +191,10 @@ int als_gs_sweep(const als_gs_sweep_params* p, void* stream);
  * items in (level, id) order (p->nitems of them).  S_idx_wait is p->S_idx with the sign bit set on
  * every edge (i -> j) that item i must wait for (j < i and j swept in this call).  publish: scratch
  * [nrows][ld] floats (nrows = rows of p->V); the call resets it and the kernel hands solved rows from
- * producer to consumer through it (each word doubles as its own "ready" flag).  err: int32[1], set to
- * 1 if a dependency wait timed out (results are then invalid). */
+ * producer to consumer through it (each word doubles as its own "ready" flag).  err: int32[2]: err[0] is set
+ * to 1 if a dependency wait timed out (results are then invalid; the caller zeroes it once); err[1] is the
+ * call's work counter (items are handed to waves through it, so the launch does not depend on all its
+ * workgroups being resident at once); the call resets it. */
 int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t* S_idx_wait, float* publish,
                           int64_t nrows, int32_t* err, void* stream);
 
@@ -300,6 +302,34 @@ int als_predict_at(int k, int ld, int64_t npairs, const int32_t* us, const int32
 int als_predict_dense(int k, int ld, int64_t m, int64_t n, const float* U,
                       const float* Z, const float* b_u, const float* b_i,
                       const double* mu, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Host-side set-up passes (HOST pointers, synchronous, no GPU involved).  They replace the reference's
+ * per-fit index-list construction (scripts/als.py:332-340) and prepare the inputs of the entry points above;
+ * the named caller times fit + predict together (scripts/evaluate_models.py:245-255), so this is inside its
+ * measured region.
+ * ------------------------------------------------------------------------- */
+/* COO ratings -> CSR by user (uptr [m+1], uidx / uval [N]) and CSC by item (iptr [n+1], iidx / ival [N]),
+ * indices ascending inside every row / column.  Returns -10 for an index outside the m x n shape, -11 for a
+ * duplicate (user, item) pair. */
+int als_host_coo_to_sides(int64_t m, int64_t n, int64_t N, const int64_t* rows, const int64_t* cols,
+                          const float* vals, int64_t* uptr, int32_t* uidx, float* uval,
+                          int64_t* iptr, int32_t* iidx, float* ival);
+
+/* Task list of als_row_solve for rows [row_begin, row_end) with at least one rating: rows longer than `chunk`
+ * (= ALS_SPLIT_CHUNK) are split, tasks are ordered longest first, whole rows of at most `mid_len` / `dual_len`
+ * ratings go last (ndual_mid / ndual_tail of als_row_solve_params).  counts[6] = {ntasks, nlong, nslots,
+ * ratings covered, ndual, nmid}; call once with tasks == NULL to size the arrays. */
+int als_host_row_tasks(const int64_t* indptr, int64_t row_begin, int64_t row_end, int32_t chunk,
+                       int32_t dual_len, int32_t mid_len, als_task* tasks, als_long_row* long_rows,
+                       int64_t* counts);
+
+/* Dependency levels of the index-ordered Gauss-Seidel sweep over the active items of [begin, end):
+ * level[n] (-1 = not swept), items in (level, id) order, offsets[nlevels + 1] (n + 1 entries provided),
+ * wait (nullable, [nnz(S)]) = the S_idx_wait input of als_gs_sweep_dataflow.  out[2] = {nitems, nlevels}. */
+int als_host_level_schedule(int64_t n, const int64_t* S_ptr, const int32_t* S_idx, const uint8_t* active,
+                            int64_t begin, int64_t end, int64_t* level, int32_t* items,
+                            int64_t* offsets, int32_t* wait, int64_t* out);
 
 #ifdef __cplusplus
 }

@@ -135,6 +135,58 @@ class NumpyBackend:
             if st is not None:
                 stat_out[i, 0], stat_out[i, 1] = float(st[0]), float(st[1])
 
+    # -- W-step (same contracts as als_w_normal_equations / als_spd_solve_f64) ------------------------------
+    @staticmethod
+    def _gram_storage(gram, i, k, ld):
+        """Item Gram in storage column order from the perm-space lower-block image the V-step wrote."""
+        pos = layout.perm_of_col(k)[:k]
+        Gp = _np(gram)[i].astype(np.float64)
+        blk = np.arange(ld) // 16
+        low = np.where(blk[:, None] >= blk[None, :], Gp, 0.0)
+        strict = np.where(blk[:, None] > blk[None, :], Gp, 0.0)
+        return (low + strict.T)[np.ix_(pos, pos)]
+
+    def w_item_vectors(self, *, k, ld, item_begin, item_end, gram, rhs, colsum, V, b_new, b_old, X, feat_off, W, H):
+        pos = layout.perm_of_col(k)[:k]
+        off = _np(feat_off)
+        Xn, Wn, Vn = _np(X).astype(np.float64), _np(W)[:, :k].astype(np.float64), _np(V)
+        for i in range(int(item_begin), int(item_end)):
+            G = self._gram_storage(gram, i, k, ld)
+            db = float(b_new[i]) - float(b_old[i])
+            ut_rho = _np(rhs)[i, pos].astype(np.float64) - db * _np(colsum)[i, pos].astype(np.float64)
+            xw = [Xn[i, off[f]:off[f + 1]] @ Wn[off[f]:off[f + 1]] for f in range(len(off) - 1)]
+            z = Vn[i, :k].astype(np.float64) + sum(xw)
+            g = ut_rho - G @ z
+            for f in range(len(off) - 1):
+                h = np.zeros(ld, dtype=np.float32)
+                h[pos] = g + G @ xw[f]
+                H[f, i] = torch.from_numpy(h)
+
+    def w_accumulate(self, *, k, ld, item_begin, item_end, gram, X, H, feat_index, feat_col0, feat_d):
+        pos = layout.perm_of_col(k)[:k]
+        d = int(feat_d)
+        A = np.zeros((d, k, d, k))
+        B = np.zeros((d, k))
+        Xn = _np(X).astype(np.float64)[:, feat_col0:feat_col0 + d]
+        for i in range(int(item_begin), int(item_end)):
+            x = Xn[i]
+            if not x.any():
+                continue
+            G = self._gram_storage(gram, i, k, ld)
+            A += np.einsum("a,b,cd->acbd", x, x, G)
+            B += np.outer(x, _np(H)[feat_index, i, pos].astype(np.float64))
+        return torch.from_numpy(A.reshape(d * k, d * k)), torch.from_numpy(B.reshape(d * k))
+
+    def spd_solve(self, A, b, diag_add, status):
+        An = _np(A) + diag_add * np.eye(A.shape[0])
+        try:
+            L = np.linalg.cholesky(An)
+        except np.linalg.LinAlgError:
+            status[0] = 1
+            return torch.zeros_like(b)
+        status[0] = 0
+        return torch.from_numpy(np.linalg.solve(L.T, np.linalg.solve(L, _np(b))))
+
     def residual_stats(self, *, k, ld, side, U, Z, b_u, b_i, mu, tasks, out):
         ptr, idx, vals = _np(side.indptr), _np(side.indices), _np(side.vals)
         Un, Zn = _np(U)[:, :k].astype(np.float64), _np(Z)[:, :k].astype(np.float64)

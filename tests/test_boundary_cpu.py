@@ -116,3 +116,37 @@ def test_cholesky_solve_host_utility():
     np.testing.assert_allclose(cholesky_solve(A, b), np.linalg.solve(A, b), rtol=1e-12)
     with pytest.raises(np.linalg.LinAlgError):
         cholesky_solve(-np.eye(3), np.ones(3))                                                 # scripts/helpers.py:19
+
+
+def test_caller_supplied_graph_is_validated():
+    """fit(..., S=csr): the sweep's level schedule relies on S being symmetric (a neighbour j > i must be on a
+    later level); an asymmetric, unsorted or out-of-range graph is refused up front with ValueError."""
+    import torch
+    from collaborative_filtering_amd.als import _check_csr, _validate_graph
+    t = torch.tensor
+    ptr, idx, val = t([0, 1, 3, 4]), t([1, 0, 2, 1], dtype=torch.int32), t([.5, .5, .25, .25])
+    _validate_graph(ptr, idx, val, 3)                                        # symmetric: accepted
+    with pytest.raises(ValueError, match="symmetric"):
+        _validate_graph(ptr, idx, t([.5, .5, .25, .3]), 3)                   # values differ across the diagonal
+    with pytest.raises(ValueError, match="symmetric"):
+        _validate_graph(t([0, 1, 2, 2]), t([1, 2], dtype=torch.int32), t([.5, .5]), 3)   # pattern not symmetric
+    with pytest.raises(ValueError, match="ascending"):
+        _validate_graph(t([0, 0, 2, 2]), t([2, 0], dtype=torch.int32), t([.5, .5]), 3)
+    with pytest.raises(ValueError, match="diagonal"):
+        _validate_graph(t([0, 1, 1, 1]), t([0], dtype=torch.int32), t([.5]), 3)
+    with pytest.raises(ValueError, match="outside"):
+        _validate_graph(t([0, 1, 1, 1]), t([7], dtype=torch.int32), t([.5]), 3)
+    with pytest.raises(ValueError, match="indptr"):
+        _check_csr(t([0, 2, 1, 3]), t([0, 1, 2], dtype=torch.int32), 3, 3, "x")
+
+
+def test_device_csr_entry_checks_index_range():
+    import torch
+    from collaborative_filtering_amd.als import _as_side
+    ptr = torch.tensor([0, 2, 3])
+    vals = torch.ones(3)
+    _as_side((ptr, torch.tensor([0, 1, 1], dtype=torch.int32), vals), 2, 2)
+    with pytest.raises(ValueError, match="outside"):
+        _as_side((ptr, torch.tensor([0, 2, 1], dtype=torch.int32), vals), 2, 2)
+    with pytest.raises(ValueError, match="outside"):
+        _as_side((ptr.numpy(), np.array([0, -1, 1], dtype=np.int32), vals.numpy()), 2, 2)

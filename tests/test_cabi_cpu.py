@@ -48,7 +48,9 @@ def test_struct_layout_matches_header(tmp_path):
     import subprocess
     from collaborative_filtering_amd import _hip
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "als_hip.h"', 'int main(void){']
-    for cname, st in (("als_row_solve_params", _hip.RowSolveParams), ("als_gs_sweep_params", _hip.GsSweepParams)):
+    structs = (("als_row_solve_params", _hip.RowSolveParams), ("als_gs_sweep_params", _hip.GsSweepParams),
+               ("als_w_params", _hip.WParams))
+    for cname, st in structs:
         src.append(f'printf("%zu\\n", sizeof({cname}));')
         for fname, _ in st._fields_:
             src.append(f'printf("%zu\\n", offsetof({cname}, {fname}));')
@@ -59,7 +61,7 @@ def test_struct_layout_matches_header(tmp_path):
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(cfile), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     vals = iter(int(x) for x in out)
-    for st in (_hip.RowSolveParams, _hip.GsSweepParams):
+    for _, st in structs:
         assert C.sizeof(st) == next(vals)
         for fname, _ in st._fields_:
             assert getattr(st, fname).offset == next(vals), (st.__name__, fname)

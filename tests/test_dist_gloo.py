@@ -36,7 +36,7 @@ def _worker(rank, world, port, name, gs_mode, outdir):
         from tests.test_gpu_parity import _model_for
         g = Golden(name)
         r, c, v = g.train
-        model = _model_for(g, device="cpu", backend=NumpyBackend(), gs_mode=gs_mode)
+        model = _model_for(g, device="cpu", backend=NumpyBackend(), gs_mode=gs_mode, process_group="world")
         model.fit_coo(r, c, v, (g.m, g.n), features=g.features or None, tol=g.cfg["tol"],
                       min_iters=g.cfg["min_iters"], verbose=0)
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), U=model.U, V=model.V, b_u=model.b_u,

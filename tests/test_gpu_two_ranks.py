@@ -33,7 +33,7 @@ def _worker(rank, world, port, name, gs_mode, outdir):
         from tests.test_gpu_parity import _model_for
         g = Golden(name)
         r, c, v = g.train
-        model = _model_for(g, device="cuda:0", gs_mode=gs_mode)
+        model = _model_for(g, device="cuda:0", gs_mode=gs_mode, process_group="world")
         model.fit_coo(r, c, v, (g.m, g.n), features=g.features or None, tol=g.cfg["tol"],
                       min_iters=g.cfg["min_iters"], verbose=0)
         assert model._eng.world == world and model._eng.multi

@@ -139,3 +139,77 @@ def test_row_tasks_three_classes(lens):
     for part in (ln[:a], ln[a:b], ln[b:]):
         assert part == sorted(part, reverse=True)
 
+
+
+# ---------------------------------------------------------------------------------------------------------
+# native set-up passes (csrc/host_setup.cpp) == the numpy definitions above, output for output
+# ---------------------------------------------------------------------------------------------------------
+def _lib():
+    import os
+    import __graft_entry__ as ge
+    from collaborative_filtering_amd import _hip
+    if not os.path.exists(_hip.LIB_PATH):
+        ge.build()
+    return _hip.load()
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.lists(st.integers(0, 60), min_size=1, max_size=60), st.integers(3, 17), st.integers(0, 12), st.integers(0, 20),
+       st.data())
+def test_native_row_tasks_equal_numpy(lens, chunk, dual_len, mid_len, data):
+    lib = _lib()
+    indptr = np.zeros(len(lens) + 1, dtype=np.int64)
+    indptr[1:] = np.cumsum(lens)
+    b = data.draw(st.integers(0, len(lens)))
+    e = data.draw(st.integers(b, len(lens)))
+    a = layout.build_row_tasks(indptr, b, e, chunk=chunk, dual_len=dual_len, mid_len=mid_len)
+    n = layout.build_row_tasks_native(lib, indptr, b, e, chunk=chunk, dual_len=dual_len, mid_len=mid_len)
+    np.testing.assert_array_equal(a.tasks, n.tasks)
+    np.testing.assert_array_equal(a.long_rows, n.long_rows)
+    assert (a.nslots, a.nnz, a.ndual, a.nmid) == (n.nslots, n.nnz, n.ndual, n.nmid)
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(1, 40), st.floats(0.0, 0.5), st.integers(0, 1000), st.data())
+def test_native_level_schedule_equals_numpy(n, p, seed, data):
+    lib = _lib()
+    rng = np.random.default_rng(seed)
+    A = np.triu(rng.random((n, n)) < p, 1)
+    A = A | A.T
+    ptr, idx, _ = layout.dense_graph_to_csr(A.astype(np.float32))
+    active = rng.random(n) < 0.8
+    b = data.draw(st.integers(0, n))
+    e = data.draw(st.integers(b, n))
+    s = layout.build_level_schedule(ptr, idx, active, b, e)
+    w = layout.wait_edges(ptr, idx, s.level)
+    sn, wn = layout.build_level_schedule_native(lib, ptr, idx, active, b, e)
+    np.testing.assert_array_equal(s.level, sn.level)
+    np.testing.assert_array_equal(s.items, sn.items)
+    np.testing.assert_array_equal(s.offsets, sn.offsets)
+    np.testing.assert_array_equal(w, wn)
+    assert layout.build_level_schedule_native(lib, ptr, idx, active, b, e, want_wait=False)[1] is None
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(1, 12), st.integers(1, 9), st.integers(0, 1000), st.booleans())
+def test_native_coo_to_sides_equals_numpy(m, n, seed, shuffled):
+    lib = _lib()
+    rng = np.random.default_rng(seed)
+    r, c = np.nonzero(rng.random((m, n)) < 0.4)
+    v = rng.integers(1, 10, size=r.size).astype(np.float32)
+    if shuffled:
+        perm = rng.permutation(r.size)
+        r, c, v = r[perm], c[perm], v[perm]
+    for a, b in zip(layout.coo_to_sides(r, c, v, (m, n)), layout.coo_to_sides_native(lib, r, c, v, (m, n))):
+        np.testing.assert_array_equal(a.indptr, b.indptr)
+        np.testing.assert_array_equal(a.indices, b.indices)
+        np.testing.assert_array_equal(a.vals, b.vals)
+
+
+def test_native_coo_to_sides_rejects_bad_input():
+    import pytest
+    lib = _lib()
+    with pytest.raises(ValueError, match="duplicate"):
+        layout.coo_to_sides_native(lib, [0, 1, 0], [1, 1, 1], [1.0, 2.0, 3.0], (2, 2))
+    with pytest.raises(ValueError, match="outside"):
+        layout.coo_to_sides_native(lib, [0, 2], [1, 1], [1.0, 2.0], (2, 2))
