@@ -9,7 +9,7 @@ per-row / per-rating step runs in the HIP kernels behind include/als_hip.h.
 
 Build-only additions (keyword arguments with defaults, so the reference
 signature is unchanged):
-  ALS(..., device=, backend=, gs_mode=, process_group=, gram=, graph_build=, hip_graph=)
+  ALS(..., device=, backend=, gs_mode=, process_group=, gram=, solve_dtype=, graph_build=, hip_graph=)
   fit(..., S=)              precomputed similarity graph as CSR (ptr, idx, val)
   fit_coo(rows, cols, vals, shape, ...)   sparse-native entry for large inputs
   predict_at(flat_idx, ...) predictions at flat indices u*n+i without the
@@ -156,13 +156,20 @@ def _tasks_to_dev(t: layout.RowTasks, device) -> _TasksDev:
                      int(t.tasks.shape[0]), int(t.long_rows.shape[0]), t.nslots, t.nnz, t.ndual, t.nmid)
 
 
+class SweepNotResident(RuntimeError):
+    """The persistent one-launch form of the Laplacian sweep (als_gs_sweep_dataflow) found some of its waves not
+    running - another kernel or process held compute units - and gave up; `ALS.fit` then refits with the
+    per-level launches, which have no residency requirement."""
+
+
 class ALS:
     """Alternating least squares with biases, feature projections and a graph
     Laplacian:  R ~ U (V + sum_f X_f W_f)^T + mu + b_u + b_i."""
 
     def __init__(self, config: ALSConfig, lambda_w: Optional[Dict[str, float]] = None, *,
                  device=None, backend=None, gs_mode: Optional[str] = None, process_group=None,
-                 gram: Optional[str] = None, graph_build: str = "host", hip_graph: bool = False) -> None:
+                 gram: Optional[str] = None, graph_build: str = "host", hip_graph: bool = False,
+                 solve_dtype: str = "float32") -> None:
         if config is None:                                   # scripts/als.py:146-147
             raise ValueError("ALSConfig must be provided.")
         self.cfg = config
@@ -194,11 +201,18 @@ class ALS:
         self._gs_mode = gs_mode
         self._pg = process_group
         self._gram = gram               # "bf16x3" (default) or "f32": how K1 forms the Gram on the matrix cores
+        # "float64": every row's normal equations are accumulated, factorised and solved in fp64 (the reference's
+        # arithmetic type) - for the small-lambda corner of the tuner's search space, where rank-deficient rows
+        # have cond ~ 1/lambda; factors stay fp32 in HBM.  Several times slower than fp32.
+        if solve_dtype not in ("float32", "float64"):
+            raise ValueError("solve_dtype must be 'float32' or 'float64'")
+        self._solve_dtype = solve_dtype
         if graph_build not in ("host", "device"):
             raise ValueError("graph_build must be 'host' (reference-identical, dense n x n) or 'device'")
         self._graph_build = graph_build
         self._hip_graph = bool(hip_graph)          # replay iterations as captured HIP graphs (one rank only)
         self._validate_S = False
+        self._dataflow_sweep = os.environ.get("ALS_GS_DATAFLOW", "1") != "0"     # persistent one-launch sweep
         self._eng: Optional[_Engine] = None
 
     # ------------------------------------------------------------------ fit
@@ -279,7 +293,7 @@ class ALS:
         backend = self._backend
         if backend is None:
             from .backend import HipBackend
-            backend = HipBackend(device, gram=self._gram or "bf16x3")
+            backend = HipBackend(device, gram=self._gram or "bf16x3", solve_dtype=self._solve_dtype)
         with _on(device):
             self._eng = _Engine(self, csr, csc, features, S_csr, device, backend, self._pg, self._gs_mode)
         if not run:                         # prepare(): the caller drives the iterations
@@ -291,7 +305,15 @@ class ALS:
                         self.lambda_v, self.pop_reg_mode, list(features), self.lambda_w,
                         self.random_state, self.alpha, self.update_w_every, self._eng.world)
         with _on(device):
-            self._eng.run(tol, min_iters, verbose)
+            try:
+                self._eng.run(tol, min_iters, verbose)
+            except SweepNotResident as e:
+                # results of the failed sweep are invalid: refit from the same initial state with one launch per
+                # dependency level (stream order is the only synchronisation they need)
+                logger.warning("%s; refitting with per-level sweep launches", e)
+                self._dataflow_sweep = False
+                self._eng = _Engine(self, csr, csc, features, S_csr, device, backend, self._pg, self._gs_mode)
+                self._eng.run(tol, min_iters, verbose)
             self._eng.export(self)
         if verbose > 0 and self.history["train_rmse"]:
             logger.info("ALS training finished. Final train RMSE: %.4f", self.history["train_rmse"][-1])
@@ -475,7 +497,7 @@ class _Engine:
                 raise ValueError(f"unknown gs_mode '{self.gs_mode}'")
             active = counts > 0
             # persistent dataflow sweep (one launch, no level barriers) when the backend has it
-            self.gs_dataflow = (hasattr(backend, "gs_dataflow")
+            self.gs_dataflow = (hasattr(backend, "gs_dataflow") and model._dataflow_sweep
                                 and not (self.multi and self.gs_mode == "levels"))
             lo, hi = (0, self.n) if (self.multi and self.gs_mode == "levels") else (self.ib, self.ie)
             if lib is not None:
@@ -489,7 +511,7 @@ class _Engine:
             if self.gs_dataflow:
                 self.S_idx_wait = torch.from_numpy(wait).to(device)
                 self.gs_publish = torch.empty(n_pad, self.ld, dtype=f32, device=device)       # same shape as V
-                self.gs_err = torch.zeros(2, dtype=torch.int32, device=device)    # [error flag, work counter]
+                self.gs_err = torch.zeros(1, dtype=torch.int32, device=device)
             self.factor = torch.zeros(n_pad * self.ld * self.ld, dtype=f32, device=device)
             self.sumr = torch.zeros(n_pad, dtype=f32, device=device)
         need_byproducts = self.use_graph or bool(self.feat_names)
@@ -553,8 +575,9 @@ class _Engine:
     def _check_status(self):
         if getattr(self, "w_bad", None) is not None and int(self.w_bad.item()):
             raise np.linalg.LinAlgError("W-step normal equations of a feature are not positive definite")
-        if getattr(self, "gs_dataflow", False) and int(self.gs_err[0].item()):
-            raise RuntimeError("Gauss-Seidel dataflow sweep: a dependency wait timed out")
+        if getattr(self, "gs_dataflow", False) and int(self.gs_err.item()):
+            raise SweepNotResident("Gauss-Seidel dataflow sweep: a dependency wait exceeded its bound (the persistent "
+                                   "launch was not resident as a whole)")
         bad = int(self.status.item())
         if bad:
             self.status.zero_()

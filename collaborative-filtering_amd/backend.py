@@ -24,12 +24,17 @@ def _p(t: Optional[torch.Tensor]):
 class HipBackend:
     name = "hip"
 
-    GRAM_MODES = {"f32": 0, "bf16x3": 1}
+    GRAM_MODES = {"f32": 0, "bf16x3": 1, "f64": 2}
 
-    def __init__(self, device: torch.device, gram: str = "bf16x3"):
-        if gram not in self.GRAM_MODES:
-            raise ValueError(f"gram must be one of {sorted(self.GRAM_MODES)}")
-        self.gram_mode = self.GRAM_MODES[gram]
+    def __init__(self, device: torch.device, gram: str = "bf16x3", solve_dtype: str = "float32"):
+        if gram not in ("f32", "bf16x3"):
+            raise ValueError("gram must be 'bf16x3' or 'f32'")
+        if solve_dtype not in ("float32", "float64"):
+            raise ValueError("solve_dtype must be 'float32' or 'float64'")
+        # solve_dtype="float64": Gram, Cholesky and substitutions of every row in fp64 (ALS_GRAM_F64); `gram` then
+        # has no effect
+        self.solve_dtype = solve_dtype
+        self.gram_mode = self.GRAM_MODES["f64" if solve_dtype == "float64" else gram]
         if device.type != "cuda":
             raise RuntimeError("HipBackend needs a ROCm device (torch device type 'cuda'); "
                                "there is no CPU path in the product")
@@ -51,6 +56,8 @@ class HipBackend:
             raise RuntimeError(f"{what} failed with status {rc} (see ALS_E_* in include/als_hip.h)")
 
     def slot_bytes(self, k: int) -> int:
+        if self.gram_mode == self.GRAM_MODES["f64"]:
+            return int(self.lib.als_partial_slot_bytes_f64(k))
         return int(self.lib.als_partial_slot_bytes(k))
 
     # -- K1 ------------------------------------------------------------------

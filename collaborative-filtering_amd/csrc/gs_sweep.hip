@@ -154,15 +154,18 @@ void k_gs_level(const als_gs_sweep_params P) {
 // ---------------------------------------------------------------------------
 // K2': the whole sweep as ONE persistent, synchronisation-free launch.
 //
-// Items are listed in (level, id) order and handed out through a ticket counter: a wave draws the next
-// position of that list with one atomic (the following ticket is drawn before the current item is worked on,
-// so the round trip is hidden).  An item waits only for the neighbours it really depends on (j < i and swept -
-// flagged by the sign bit of `Sw`); there is no level barrier.  Progress needs NO co-residency of the grid:
-// an item is only ever held by a wave that is running, tickets rise inside a wave, so the earliest unfinished
-// item of the global order is some running wave's current item and all its dependencies (earlier items) are
-// finished.  Workgroups that start late - another kernel or process occupying CUs - simply find higher
-// tickets (a static round-robin deal would leave their items unowned while the resident waves spin on them).
-// Which wave solves an item has no influence on the result.
+// Items are listed in (level, id) order and dealt round-robin to the `nwaves` waves of the launch; each wave
+// walks its items in that order.  An item waits only for the neighbours it really depends on (j < i and
+// swept - flagged by the sign bit of `Sw`); there is no level barrier.  Progress: the earliest unfinished
+// item in the global order has all dependencies finished and is the next item of its wave - provided that
+// wave is running.  The grid is sized to fit the device at once (occupancy query, per device), so every wave
+// is resident unless something else holds CUs (a kernel of another stream or process); its workgroups then
+// start when that something ends, the resident waves spin meanwhile.  Every spin is bounded (SPIN_LIMIT,
+// ~40 ms - two orders of magnitude above a legitimate hop): on expiry the wave raises `err`, every other wave
+// bails out at its next poll, and the caller falls back to the per-level launches (als_gs_sweep_levels),
+// which need no co-residency.  (A ticket counter handing items to whichever wave is free needs no residency
+// assumption at all, but 10^5 device-scope atomics on one address serialise at ~75 ns each: measured 7.7 ms
+// per sweep at cfg 4 against 1.46 ms.)
 //
 // Hand-off: solved rows travel through the publication buffer `pub` (same shape as V), every word of which
 // the launcher resets to GS_SENTINEL.  A producer stores its row there with agent-scope (sc1, write-
@@ -200,35 +203,26 @@ struct DfCfg {
 template <int KB, bool STREAM>
 __global__ __launch_bounds__((64 * DfCfg<KB, STREAM>::WPW), (DfCfg<KB, STREAM>::IMAGE ? 1 : 2))
 void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, float* pub,
-                   int32_t* err, int64_t nitems) {
+                   int32_t* err, int64_t nitems, int nwaves) {
     using C = KCfg<KB>;
     constexpr int KP = C::KP, NR = C::NR;
     using D = DfCfg<KB, STREAM>;
     constexpr int LD = D::LD;
     constexpr bool IMAGE = D::IMAGE;
-    constexpr unsigned long long SPIN_LIMIT = 1ull << 28;      // ~2.7 s of the 100 MHz memtime clock
+    constexpr unsigned long long SPIN_LIMIT = 1ull << 22;      // ~42 ms of the 100 MHz memtime clock
     __shared__ float lds_img[D::IMG];
     float* Al = lds_img;
     float* vec = lds_img + (IMAGE ? KP * LD : 0);
     float* dinv = vec + (IMAGE ? 2 * KP : 0);
     const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * D::WPW + (threadIdx.x >> 6);
     int ic[NR], col[NR];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
         ic[rr] = min(lane + 64 * rr, KP - 1);
         col[rr] = perm_to_col<KB>(ic[rr]);
     }
-    int32_t* ticket = err + 1;                       // zeroed by the launcher
-    auto draw = [&]() -> int {
-        int t = 0;
-        if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return t;                                    // lane 0 holds the ticket; read with readfirstlane when needed
-    };
-    int t_next = draw();
-    for (;;) {
-        const int64_t it = __builtin_amdgcn_readfirstlane(t_next);
-        if (it >= nitems) break;
-        t_next = draw();                             // in flight underneath this item's work
+    for (int64_t it = gw; it < nitems; it += nwaves) {
         const int item = P.items[it];
         const int64_t i64 = item;
         const int64_t s0 = P.S_ptr[item], s1 = P.S_ptr[item + 1];
@@ -465,12 +459,11 @@ int launch_gs_dataflow_as(const als_gs_sweep_params* p, const int32_t* Sw, float
         per_cu_of[dev].store(per_cu, std::memory_order_relaxed);
     }
     if (waves_out) { *waves_out = ncu * per_cu * WPW; return 0; }
-    // the grid fills the device once (more workgroups would only queue up behind the resident ones); the ticket
-    // counter makes the sweep correct for ANY number of resident workgroups
     int nwg = ncu * per_cu;
     if ((int64_t)nwg * WPW > nitems) nwg = (int)((nitems + WPW - 1) / WPW);
     if (nwg < 1) return 0;
-    hipLaunchKernelGGL((k_gs_dataflow<KB, STREAM>), dim3(nwg), dim3(64 * WPW), 0, st, *p, Sw, pub, err, nitems);
+    hipLaunchKernelGGL((k_gs_dataflow<KB, STREAM>), dim3(nwg), dim3(64 * WPW), 0, st, *p, Sw, pub, err, nitems,
+                       nwg * WPW);
     return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
 }
 
@@ -511,8 +504,7 @@ extern "C" int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t
     if (p->stat_out && (!p->sumr2 || !p->lambda_eff)) return ALS_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (p->nitems > 0 && nrows > 0 &&
-        (hipMemsetD32Async((hipDeviceptr_t)publish, (int)GS_SENTINEL, (size_t)nrows * ld, st) != hipSuccess ||
-         hipMemsetD32Async((hipDeviceptr_t)(err + 1), 0, 1, st) != hipSuccess))          // ticket counter
+        hipMemsetD32Async((hipDeviceptr_t)publish, (int)GS_SENTINEL, (size_t)nrows * ld, st) != hipSuccess)
         return ALS_E_LAUNCH;
     switch (ld / 16) {
         case 1: return launch_gs_dataflow<1>(p, S_idx_wait, publish, err, p->nitems, st);

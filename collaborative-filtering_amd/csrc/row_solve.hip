@@ -953,6 +953,8 @@ int launch_row_solve(const als_row_solve_params* p, hipStream_t st) {
 
 }  // namespace
 
+int als_row_solve_f64_dispatch(const als_row_solve_params* p, hipStream_t st);     // row_solve_f64.hip
+
 extern "C" int als_version(void) { return ALS_HIP_VERSION; }
 extern "C" int als_padded_k(int k) { return (k < 1 || k > ALS_MAX_K) ? ALS_E_BADK : 16 * ((k + 15) / 16); }
 extern "C" int als_perm_index(int k, int c) {
@@ -974,7 +976,7 @@ extern "C" int als_row_solve(const als_row_solve_params* p, void* stream) {
     if (ld < 0) return ALS_E_BADK;
     if (p->ld != ld || !p->indptr || !p->indices || !p->vals || !p->F || !p->bias_self ||
         !p->bias_other || !p->mu || !p->status || p->ntasks < 0 || p->nlong < 0 || p->F_zero_row < 0 ||
-        (p->gram_mode != ALS_GRAM_F32 && p->gram_mode != ALS_GRAM_BF16X3) ||
+        (p->gram_mode != ALS_GRAM_F32 && p->gram_mode != ALS_GRAM_BF16X3 && p->gram_mode != ALS_GRAM_F64) ||
         (int64_t)p->F_zero_row * ld >= ((int64_t)1 << 31))
         return ALS_E_BADARG;
     if (p->ntasks > 0 && !p->tasks) return ALS_E_BADARG;
@@ -985,6 +987,7 @@ extern "C" int als_row_solve(const als_row_solve_params* p, void* stream) {
         return ALS_E_BADARG;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (p->gram_mode == ALS_GRAM_F64) return als_row_solve_f64_dispatch(p, st);
     switch (ld / 16) {
         case 1: return launch_row_solve<1>(p, st);
         case 2: return launch_row_solve<2>(p, st);

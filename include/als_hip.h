@@ -42,6 +42,8 @@ extern "C" {
 
 #define ALS_GRAM_F32    0
 #define ALS_GRAM_BF16X3 1
+#define ALS_GRAM_F64    2     /* fp64 Gram (v_mfma_f64_16x16x4_f64), fp64 Cholesky and substitutions: the
+                                 reference's arithmetic type; x and the bias are rounded to fp32 on store */
 
 #define ALS_MAX_K 160
 #define ALS_SPLIT_CHUNK 4096  /* ratings per task segment (see als_task) */
@@ -70,6 +72,7 @@ int als_padded_k(int k);                       /* ld for k factors            */
 int als_perm_index(int k, int c);              /* perm-space position of col c */
 /* bytes of one partial slot / of the whole workspace for `nslots` slots */
 int64_t als_partial_slot_bytes(int k);
+int64_t als_partial_slot_bytes_f64(int k);     /* slot size when gram_mode == ALS_GRAM_F64 */
 
 /* ---------------------------------------------------------------------------
  * als_row_solve - normal-equation build and solve for a set of rows.
@@ -118,7 +121,11 @@ typedef struct als_row_solve_params {
     int32_t gram_mode;          /* ALS_GRAM_F32: v_mfma_f32_16x16x4_f32 on the gathered floats;
                                    ALS_GRAM_BF16X3: exact 3-way bf16 split of every float, six cross
                                    products on v_mfma_f32_16x16x32_bf16, fp32 accumulate (same accuracy
-                                   class, the matrix cores run beside the VALU) */
+                                   class, the matrix cores run beside the VALU);
+                                   ALS_GRAM_F64: everything in fp64 (row_solve_f64.hip) - for lambda << 1 with
+                                   rank-deficient rows, where cond(A) ~ 1/lambda amplifies the fp32 rounding of
+                                   the Gram; workspace slots are als_partial_slot_bytes_f64(k) bytes; the
+                                   dual-form classes are ignored */
     int32_t ndual_tail;         /* number of TRAILING tasks that are whole rows (slot < 0) of at most 64 ratings
                                    to be solved in the dual form (n x n instead of k x k system, same
                                    solution); honoured in plain solve calls (no by-product outputs, no
@@ -191,10 +198,10 @@ int als_gs_sweep(const als_gs_sweep_params* p, void* stream);
  * items in (level, id) order (p->nitems of them).  S_idx_wait is p->S_idx with the sign bit set on
  * every edge (i -> j) that item i must wait for (j < i and j swept in this call).  publish: scratch
  * [nrows][ld] floats (nrows = rows of p->V); the call resets it and the kernel hands solved rows from
- * producer to consumer through it (each word doubles as its own "ready" flag).  err: int32[2]: err[0] is set
- * to 1 if a dependency wait timed out (results are then invalid; the caller zeroes it once); err[1] is the
- * call's work counter (items are handed to waves through it, so the launch does not depend on all its
- * workgroups being resident at once); the call resets it. */
+ * producer to consumer through it (each word doubles as its own "ready" flag).  err: int32[1], the caller
+ * zeroes it once; set to 1 when a dependency wait exceeded its bound (~40 ms: the launch was not resident as a
+ * whole because something else held compute units).  Results are then invalid and the caller should redo the
+ * sweep - from the state before it - with als_gs_sweep_levels, which has no residency requirement. */
 int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t* S_idx_wait, float* publish,
                           int64_t nrows, int32_t* err, void* stream);
 

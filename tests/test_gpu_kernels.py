@@ -8,6 +8,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _env(gram="bf16x3"):
+    solve_dtype = "float64" if gram == "f64" else "float32"      # "f64": ALS_GRAM_F64 (row_solve_f64.hip)
+    gram = "bf16x3" if gram == "f64" else gram
     import torch
     if not torch.cuda.is_available():
         pytest.fail("GPU tests selected (-m gpu) but no ROCm device is visible")
@@ -15,7 +17,7 @@ def _env(gram="bf16x3"):
     from collaborative_filtering_amd.als import _side_to_dev, _tasks_to_dev
     from collaborative_filtering_amd.backend import HipBackend
     dev = torch.device("cuda", 0)
-    return torch, layout, _side_to_dev, _tasks_to_dev, HipBackend(dev, gram=gram), dev
+    return torch, layout, _side_to_dev, _tasks_to_dev, HipBackend(dev, gram=gram, solve_dtype=solve_dtype), dev
 
 
 def _random_side(layout, nrows, ncols, lens, seed):
@@ -34,10 +36,12 @@ def _pad(A, ld, extra_rows=0):
     return out
 
 
-@pytest.mark.parametrize("gram", ["bf16x3", "f32"])
+@pytest.mark.parametrize("gram", ["bf16x3", "f32", "f64"])
 @pytest.mark.parametrize("k", [1, 16, 32, 50, 64, 80, 96, 112, 128, 160])
 def test_row_solve_against_numpy(k, gram):
     torch, layout, side_dev, tasks_dev, be, dev = _env(gram)
+    # fp32 solve: rtol 2e-3 / 2e-4 of max|x|; fp64 solve: what is left is the fp32 rounding of the stored x
+    xr, xa, ba, gr, ga = (2e-6, 2e-6, 2e-6, 2e-7, 2e-7) if gram == "f64" else (2e-3, 2e-4, 2e-4, 1e-4, 1e-5)
     ncols = 9000
     lens = [1, 2, 0, k // 2 + 1, k, 3 * k + 5, 700, 0, 4096, 4097, 8200 + k, 33, 64, 65, 5]
     nrows = len(lens)
@@ -89,22 +93,76 @@ def test_row_solve_against_numpy(k, gram):
         b = Fr.T @ rr + rhs_extra.astype(np.float32)[r]
         x = np.linalg.solve(A, b)
         scale = max(np.max(np.abs(x)), 1e-6)
-        np.testing.assert_allclose(X[r, :k], x, rtol=2e-3, atol=2e-4 * scale, err_msg=f"row {r} nnz {hi - lo}")
+        np.testing.assert_allclose(X[r, :k], x, rtol=xr, atol=xa * scale, err_msg=f"row {r} nnz {hi - lo}")
         assert np.all(X[r, k:] == 0.0)
         bref = np.sum(vals - Fr @ x - mu - b_other.astype(np.float32)[idx]) / ((hi - lo) + lam_b + 1e-10)
-        assert abs(bias[r] - bref) <= 2e-4 * max(1.0, abs(bref)), (r, bias[r], bref)
+        assert abs(bias[r] - bref) <= ba * max(1.0, abs(bref)), (r, bias[r], bref)
         Gr = G[r][np.ix_(pos, pos)]
         blk = pos // 16
         lower_block = blk[:, None] >= blk[None, :]            # documented valid region
         ref = Fr.T @ Fr
-        np.testing.assert_allclose(Gr[lower_block], ref[lower_block], rtol=1e-4,
-                                   atol=1e-5 * max(np.max(np.abs(ref)), 1e-6))
+        np.testing.assert_allclose(Gr[lower_block], ref[lower_block], rtol=gr,
+                                   atol=ga * max(np.max(np.abs(ref)), 1e-6))
 
 
+@pytest.mark.parametrize("k", [16, 50, 64, 128])
+def test_row_solve_f64_small_lambda(k):
+    """ALS_GRAM_F64 at lambda = 1e-4 with rows shorter than k (cond ~ 1/lambda, where the fp32 kernels lose the
+    null-space components): the fp64 kernel returns numpy's float64 solution up to the fp32 rounding of the
+    stored x, and the closed-form residual statistics equal the directly evaluated sums."""
+    torch, layout, side_dev, tasks_dev, be, dev = _env("f64")
+    ncols = 5000
+    lens = [1, 3, k // 2 + 1, max(k - 1, 1), k, k + 7, 300, 4100, 17, 2]
+    nrows = len(lens)
+    side = _random_side(layout, nrows, ncols, lens, seed=900 + k)
+    rng = np.random.default_rng(950 + k)
+    ld = layout.padded_k(k)
+    F = rng.normal(scale=0.3, size=(ncols, k)).astype(np.float32)
+    b_self = rng.normal(scale=0.2, size=nrows).astype(np.float32)
+    b_other = rng.normal(scale=0.2, size=ncols).astype(np.float32)
+    mu, lam, lam_b = 3.3, 1e-4, 1.7
+    t = layout.build_row_tasks(side.indptr)
+    sd, td = side_dev(side, dev), tasks_dev(t, dev)
+    f32 = torch.float32
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    X_out = torch.zeros(nrows, ld, dtype=f32, device=dev)
+    bias_out = torch.zeros(nrows, dtype=f32, device=dev)
+    stat = torch.zeros(nrows, 2, dtype=f32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(max(t.nslots, 1) * be.slot_bytes(k) // 4, dtype=f32, device=dev)
+    be.row_solve(k=k, ld=ld, side=sd, F=tt(_pad(F, ld, 1)), zero_row=ncols, bias_self=tt(b_self), bias_other=tt(b_other),
+                 mu=torch.tensor([mu], dtype=torch.float64, device=dev), lam=lam, lam_row=None, lam_b=lam_b,
+                 lam_b_row=None, rhs_extra=None, diag_extra=None, X_out=X_out, bias_out=bias_out, gram_out=None,
+                 factor_out=None, rhs_out=None, colsum_out=None, sumr_out=None, status=status, tasks=td, workspace=ws,
+                 stat_out=stat)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    X = X_out.cpu().numpy().astype(np.float64)
+    bias = bias_out.cpu().numpy().astype(np.float64)
+    st = stat.cpu().numpy().astype(np.float64)
+    F64 = F.astype(np.float64)
+    for r in range(nrows):
+        lo, hi = side.indptr[r], side.indptr[r + 1]
+        idx = side.indices[lo:hi]
+        Fr = F64[idx]
+        vals = side.vals[lo:hi].astype(np.float64)
+        rho = vals - mu - b_other[idx].astype(np.float64)
+        A = Fr.T @ Fr + (np.float32(lam).astype(np.float64) + 1e-10) * np.eye(k)
+        x = np.linalg.solve(A, Fr.T @ (rho - np.float64(b_self[r])))
+        scale = max(np.max(np.abs(x)), 1e-6)
+        np.testing.assert_allclose(X[r, :k], x, rtol=5e-6, atol=5e-6 * scale, err_msg=f"row {r} nnz {hi - lo}")
+        bref = np.sum(rho - Fr @ x) / ((hi - lo) + lam_b + 1e-10)
+        assert abs(bias[r] - bref) <= 2e-6 * max(1.0, abs(bref)), (r, bias[r], bref)
+        d = rho - Fr @ x - bref
+        assert abs(st[r, 0] - d.sum()) <= 1e-5 * max(1.0, np.abs(rho).sum())
+        assert abs(st[r, 1] - (d * d).sum()) <= 1e-5 * max(1e-3, (d * d).sum()) + 1e-9 * (rho * rho).sum()
+
+
+@pytest.mark.parametrize("gram", ["bf16x3", "f64"])
 @pytest.mark.parametrize("k", [16, 64, 80, 96, 128, 160])
-def test_factor_mode_and_gs_level(k):
+def test_factor_mode_and_gs_level(k, gram):
     """factor-only als_row_solve + als_gs_sweep on one level == direct solve with the graph term."""
-    torch, layout, side_dev, tasks_dev, be, dev = _env()
+    torch, layout, side_dev, tasks_dev, be, dev = _env(gram)
     ncols, nrows = 6000, 40
     rng = np.random.default_rng(7 + k)
     lens = list(rng.integers(1, 300, size=nrows))
