@@ -142,30 +142,45 @@ def gen_features(n, seed):
     return {"genres": G, "years": ((y - y.mean()) / y.std()).astype(np.float32)}
 
 
+def _sample_rows(ptr_d, idx_d, val_d, nrows, cap_ratings, seed, dev):
+    """A seeded uniform random sample of rows (without replacement, in random order) holding about
+    `cap_ratings` ratings: (row ids, compact indptr, indices, values) on the host."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    perm = torch.randperm(nrows, generator=g).to(dev)
+    lens = (ptr_d[1:] - ptr_d[:-1])[perm]
+    csum = torch.cumsum(lens, 0)
+    take = int(torch.searchsorted(csum, torch.tensor([cap_ratings], device=dev)).item()) + 1
+    take = max(1, min(take, nrows))
+    rows, lens = perm[:take], lens[:take]
+    ptr = torch.zeros(take + 1, dtype=torch.int64, device=dev)
+    ptr[1:] = torch.cumsum(lens, 0)
+    pos = torch.repeat_interleave(ptr_d[rows] - ptr[:-1], lens) + torch.arange(int(ptr[-1]), device=dev)
+    return rows.cpu().numpy(), ptr.cpu().numpy(), idx_d[pos].cpu().numpy().astype(np.int64), val_d[pos].double().cpu().numpy()
+
+
 def cpu_baseline(eng, budget_s=20.0):
-    """The oracle (numpy port of the reference's per-row loops, float64) on a bounded
-    sample of the same workload: the first rows of the U-step and of the V-step that fit
-    the time budget.  ratings/s per iteration = 1 / (s per rating of U-step + of V-step)."""
+    """The oracle (numpy port of the reference's per-row loops, float64) on a bounded RANDOM sample of the same
+    workload: seeded uniform samples of users (U-step) and of items (V-step, with the Laplacian term), worked
+    through in random order until the time budget is spent.  ratings/s per iteration = 1 / (s per rating of the
+    U-step + s per rating of the V-step)."""
     from oracle.als_oracle import OracleALS, OracleConfig, Ratings
     md = eng.model
     k = eng.k
     o = OracleALS(OracleConfig(n_factors=k, n_iters=1, lambda_u=md.lambda_u, lambda_v=md.lambda_v,
                                lambda_bu=md.lambda_bu, lambda_bi=md.lambda_bi, alpha=md.alpha,
                                sim={"feature_name": "genres"} if eng.use_graph else None))
-    uptr = eng.csr.indptr.cpu().numpy()
-    iptr = eng.csc.indptr.cpu().numpy()
     V = eng.V[: eng.n, :k].double().cpu().numpy()
     b_i = eng.b_i[: eng.n].double().cpu().numpy()
     mu = float(eng.mu.item())
-    # ---- users: rows [0, su)
-    su = int(np.searchsorted(uptr, 12_000_000))
-    su = max(1, min(su, eng.m))
-    nu = int(uptr[su])
-    rt = Ratings(su, eng.n, None, eng.csr.indices[:nu].cpu().numpy().astype(np.int64),
-                 eng.csr.vals[:nu].double().cpu().numpy(), uptr[: su + 1].copy(), None, None, None)
+    cap = 6_000_000
+    # ---- users: a random sample, as a compact CSR over all items
+    urows, uptr, uidx, uval = _sample_rows(eng.csr.indptr, eng.csr.indices, eng.csr.vals, eng.m, cap, 4001, eng.dev)
+    su = urows.size
+    rt = Ratings(su, eng.n, None, uidx, uval, uptr, None, None, None)
     o.mu, o.V, o.b_i = mu, V, b_i
     o.U = np.zeros((su, k))
-    o.b_u = np.zeros(su)
+    o.b_u = eng.b_u[torch.from_numpy(urows).to(eng.dev)].double().cpu().numpy()
     t0 = time.perf_counter()
     done_u, rows_u = 0, 0
     for blk in range(0, su, 256):
@@ -175,18 +190,23 @@ def cpu_baseline(eng, budget_s=20.0):
         if time.perf_counter() - t0 > budget_s / 2:
             break
     tu = time.perf_counter() - t0
-    # ---- items: columns [0, si) with users remapped to a compact range
-    si = int(np.searchsorted(iptr, 12_000_000))
-    si = max(1, min(si, eng.n))
-    ni = int(iptr[si])
-    users = eng.csc.indices[:ni].cpu().numpy().astype(np.int64)
-    uniq, compact = np.unique(users, return_inverse=True)
+    # ---- items: a random sample of columns; users remapped to a compact range, item ids kept (graph rows)
+    irows, iptr, iusers, ival = _sample_rows(eng.csc.indptr, eng.csc.indices, eng.csc.vals, eng.n, cap, 4002, eng.dev)
+    si = irows.size
+    uniq, compact = np.unique(iusers, return_inverse=True)
     o.U = eng.U[torch.from_numpy(uniq).to(eng.dev), :k].double().cpu().numpy()
     o.b_u = eng.b_u[torch.from_numpy(uniq).to(eng.dev)].double().cpu().numpy()
     o.V = V.copy()
     o.b_i = b_i.copy()
-    rt2 = Ratings(uniq.size, si, None, None, None, None, iptr[: si + 1].copy(), compact,
-                  eng.csc.vals[:ni].double().cpu().numpy())
+    # scatter the sampled columns back to their item ids (empty columns elsewhere): the Laplacian term of item i
+    # then reads the real neighbours of i
+    cnt = np.zeros(eng.n, dtype=np.int64)
+    cnt[irows] = np.diff(iptr)
+    full_ptr = np.zeros(eng.n + 1, dtype=np.int64)
+    np.cumsum(cnt, out=full_ptr[1:])
+    order = np.argsort(irows, kind="stable")
+    src = np.concatenate([np.arange(iptr[j], iptr[j + 1]) for j in order]) if si else np.zeros(0, np.int64)
+    rt2 = Ratings(uniq.size, eng.n, None, None, None, None, full_ptr, compact[src], ival[src])
     o.lambda_v_i = np.full(eng.n, float(md.lambda_v))
     o.lambda_bi_i = np.full(eng.n, float(md.lambda_bi))
     o.use_graph = eng.use_graph
@@ -196,7 +216,7 @@ def cpu_baseline(eng, budget_s=20.0):
     t0 = time.perf_counter()
     done_i, cols_i = 0, 0
     for blk in range(0, si, 32):
-        o.item_step(rt2, cols=range(blk, min(blk + 32, si)))
+        o.item_step(rt2, cols=[int(c) for c in irows[blk:blk + 32]])
         cols_i = min(blk + 32, si)
         done_i = int(iptr[cols_i])
         if time.perf_counter() - t0 > budget_s / 2:
@@ -205,9 +225,9 @@ def cpu_baseline(eng, budget_s=20.0):
     per_rating = tu / max(done_u, 1) + tv / max(done_i, 1)
     return {"value": 1.0 / per_rating, "unit": "ratings/s per ALS iteration",
             "cores": 1, "kind": "port",
-            "sample": (f"oracle/als_oracle.py (float64 numpy+scipy per-row loop): U-step over the first "
-                       f"{rows_u} users ({done_u} ratings, {tu:.1f} s) + V-step with Laplacian term over the "
-                       f"first {cols_i} items ({done_i} ratings, {tv:.1f} s); host has {os.cpu_count()} cores, "
+            "sample": (f"oracle/als_oracle.py (float64 numpy+scipy per-row loop) on seeded uniform random row samples: "
+                       f"U-step over {rows_u} random users ({done_u} ratings, {tu:.1f} s) + V-step with Laplacian term "
+                       f"over {cols_i} random items ({done_i} ratings, {tv:.1f} s); host has {os.cpu_count()} cores, "
                        f"loop is single-threaded")}
 
 
@@ -226,6 +246,8 @@ def main():
     ap.add_argument("--gram", default="bf16x3", choices=["bf16x3", "f32"],
                     help="how K1 forms the Gram: exact 3-way bf16 split on the bf16 matrix cores (fp32 "
                          "accumulate, fp32-level accuracy) or v_mfma_f32 on the raw floats")
+    ap.add_argument("--solve-dtype", default="float32", choices=["float32", "float64"],
+                    help="float64: fp64 Gram / Cholesky / substitutions per row (accuracy mode; NOT the headline dtype)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N>1 code path with several ranks on ONE GPU")
     args = ap.parse_args()
@@ -290,7 +312,7 @@ def main():
                            if S is not None else GraphConfig()))
     model = ALS(cfg, lambda_w={"genres": 5.0, "years": 10.0} if features else None,
                 device=dev, gs_mode=args.gs_mode, gram=args.gram, hip_graph=args.hip_graph,
-                process_group="world" if dist_on else None)
+                solve_dtype=args.solve_dtype, process_group="world" if dist_on else None)
     eng = model.prepare_csr(csr, csc, (m, n), features=features, S=S)
     if features:
         eng.be.compose_z(eng.V, eng.Xcat, eng.Wcat, eng.Z)
@@ -340,40 +362,55 @@ def main():
         # Primary view: HBM.  With the Gram on the bf16 matrix cores the binding resources of this kernel are
         # the gather of 256-B factor rows (V-step launch: U does not fit the caches) and VALU issue (U-step
         # launch); the fp32-matrix view (k = 64 was fp32-MFMA-bound) is kept as `mfma_view`.
+        # the iteration's algorithmic bytes over the whole iteration time
+        by_iter = 2 * (4 * k + 12) * nnz + (m + n) * (4 * k + 12)
         roof = {"kernel": f"k_row_tasks<KB={-(-k // 16)}> (als_row_solve; U-step and V-step launches"
                           + ("; short rows of the U-step in k_row_dual" if k > 64 else "") + ")",
                 "bound": "hbm", "achieved": by / t_rs / 1e9, "peak": 8000.0, "unit": "GB/s",
                 "frac": by / t_rs / 1e9 / 8000.0,
+                "frac_note": "algorithmic bytes per launch / average launch duration of the dominant kernel",
+                "frac_iter": by_iter / (elapsed / args.steps) / 1e9 / 8000.0,
+                "frac_iter_note": "SURVEY 8(d): [2(4k+12)N + (m+n)(4k+12)] / t_iter / 8 TB/s (whole iteration)",
                 "avg_launch_ms": 1e3 * t_rs / n_launch,
                 "algorithmic_bytes_per_launch": by / n_launch,
                 "per_launch": {nm: {"ms": sum(phase.get(nm, [0.0])) / args.steps,
-                                    "algorithmic_GBps": (4 * k + 12) * (nn + rr) / (1e-3 * sum(phase.get(nm, [1e-9])) / args.steps) / 1e9}
+                                    "algorithmic_GBps": (4 * k + 12) * (nn + rr) / (1e-3 * sum(phase.get(nm, [1e-9])) / args.steps) / 1e9,
+                                    "frac": (4 * k + 12) * (nn + rr) / (1e-3 * sum(phase.get(nm, [1e-9])) / args.steps) / 1e9 / 8000.0}
                                for nm, nn, rr in (("row_solve_user", nn_u, rows_u), ("row_solve_item", nn_i, rows_i))},
-                "mfma_view": {"achieved_TFLOPs": fl / t_rs / 1e12, "peak_TFLOPs": 157.3, "frac": fl / t_rs / 1e12 / 157.3,
-                              "algorithmic_flops_per_launch": fl / n_launch,
-                              "note": "full-Gram fp32 flops of SURVEY 8(d) against the dense fp32 matrix peak; the kernel "
-                                      "issues 10/16 of them, in gram=bf16x3 mode as 6 bf16 MFMAs per block"},
                 "traffic": None}
-        # HBM bytes per launch from the committed PMC pass (profiles/collect_pmc.sh; FETCH_SIZE doubled as
-        # MI355X_MICROARCH.md prescribes for gfx950) - only meaningful for the workload it was taken on
+        # matrix-core view: flops the kernel actually ISSUES.  bf16x3 mode: the 10 of 16 lower Gram blocks, six
+        # bf16 MFMAs per block (exact 3-way split) -> 6 * (10/16) * 2 k^2 flops per rating, against the dense bf16
+        # peak; f32 mode: (10/16) * 2 k^2 on v_mfma_f32 against the fp32 matrix peak.  (For k != 64 the block count
+        # is KB(KB+1)/2 of KB^2.)
+        kb = -(-k // 16)
+        sym = (kb * (kb + 1) / 2) / (kb * kb)
+        if args.solve_dtype == "float64":
+            issued, peak_tf, what = sym * 2 * (16 * kb) ** 2 * (nn_u + nn_i), 78.6, "fp64 MFMA flops issued / dense fp64 matrix peak"
+        elif args.gram == "bf16x3":
+            issued, peak_tf, what = 6 * sym * 2 * (16 * kb) ** 2 * (nn_u + nn_i), 2500.0, "bf16 MFMA flops issued (6 per Gram product) / dense bf16 peak"
+        else:
+            issued, peak_tf, what = sym * 2 * (16 * kb) ** 2 * (nn_u + nn_i), 157.3, "fp32 MFMA flops issued / dense fp32 matrix peak"
+        roof["mfma_view"] = {"issued_TFLOPs": issued / t_rs / 1e12, "peak_TFLOPs": peak_tf,
+                             "frac": issued / t_rs / 1e12 / peak_tf, "what": what,
+                             "algorithmic_full_gram_fp32_TFLOPs": fl / t_rs / 1e12}
+        # HBM bytes per launch: NOT measured in this run - taken from the committed PMC pass of the same workload
+        # (profiles/collect_pmc.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
         import glob
         pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_row_tasks.json")))
-        if pm and args.size == "cfg4" and world == 1:
+        if pm and args.size == "cfg4" and world == 1 and args.solve_dtype == "float32":
             roof["traffic"] = json.load(open(pm[-1]))["traffic_bytes_per_launch_mean"]
-            roof["traffic_source"] = os.path.relpath(pm[-1], ROOT)
-        # the kernel exploits the symmetry of the Gram (10 of 16 blocks): matrix-core work actually issued
-        fl_exec = (2 * k * k * 10 / 16 + 4 * k) * (nn_u + nn_i)
-        roof["mfma_view"]["executed_gram_frac_of_fp32_peak"] = fl_exec / t_rs / 1e12 / 157.3
+            roof["traffic_source"] = "from_profile: " + os.path.relpath(pm[-1], ROOT) + " (not measured in this run)"
         out = {
             "metric": "ratings/sec per ALS iteration at k=64", "value": nnz / (elapsed / args.steps),
             "unit": "ratings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": ("f32 (storage, solve, accumulate); Gram products as exact 3-way bf16 split on bf16 MFMA"
+            "dtype": ("f32 storage; f64 Gram / Cholesky / substitutions (solve_dtype=float64)" if args.solve_dtype == "float64"
+                      else "f32 (storage, solve, accumulate); Gram products as exact 3-way bf16 split on bf16 MFMA"
                       if args.gram == "bf16x3" else "f32"), "data": "synthetic",
             "config": {"workload": f"{args.size}: {m} users x {n} items, {nnz} ratings, k={k}, bias + "
                                    f"graph-Laplacian (alpha=0.5, {0 if S is None else int(S[1].numel())} graph nnz)"
                                    + (" [BASELINE.json configs[3]]" if args.size == "cfg4" else ""),
-                       "gram": args.gram, "hip_graph": bool(args.hip_graph), "gs_mode": getattr(eng, "gs_mode", None), "gs_levels": (len(eng.sched.offsets) - 1)
+                       "gram": args.gram, "solve_dtype": args.solve_dtype, "hip_graph": bool(args.hip_graph), "gs_mode": getattr(eng, "gs_mode", None), "gs_levels": (len(eng.sched.offsets) - 1)
                        if eng.use_graph else 0,
                        "parallelism": f"users/items sharded x{world}, all-gather of factor blocks",
                        "setup_s": t_setup},

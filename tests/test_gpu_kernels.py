@@ -89,7 +89,7 @@ def test_row_solve_against_numpy(k, gram):
         Fr = F32[idx]
         vals = side.vals[lo:hi].astype(np.float64)
         rr = vals - (mu + np.float32(b_self[r]) + b_other.astype(np.float32)[idx])
-        A = Fr.T @ Fr + (np.float32(lam_row[r]) + 1e-10 + np.float32(diag_extra[r])) * np.eye(k)
+        A = Fr.T @ Fr + (float(np.float32(lam_row[r])) + 1e-10 + float(np.float32(diag_extra[r]))) * np.eye(k)
         b = Fr.T @ rr + rhs_extra.astype(np.float32)[r]
         x = np.linalg.solve(A, b)
         scale = max(np.max(np.abs(x)), 1e-6)

@@ -56,8 +56,10 @@ TOL_OVERRIDES = {
 }
 
 
-# solve_dtype="float64": the fp32 storage of U, V, b between half-steps is what is left
-TOL_F64 = {}
+# solve_dtype="float64": what is left is the fp32 storage of U, V, b between half-steps (and, with features / the
+# Laplacian, the fp32 item Grams of the W-step and the fp32 triangular solves of the sweep).  Observed over all
+# fixtures: history <= 7e-9, fold test RMSE <= 9e-9, biases <= 6e-8, mu <= 7e-9, factors <= 5.3e-6 of max|ref|.
+TOL64 = dict(hist=1e-7, norms=2e-6, test_rmse=1e-7, f_rtol=1e-4, f_atol=5e-5, bias=1e-6, mu=1e-7, pred=5e-5)
 
 
 def _close(got, ref, rtol=TOL["f_rtol"], atol_rel=TOL["f_atol"], what=""):
@@ -123,7 +125,7 @@ def test_fit_float64_matches_reference_fixture(name):
     r, c, v = g.train
     model.fit_coo(r, c, v, (g.m, g.n), features=g.features or None, tol=g.cfg["tol"],
                   min_iters=g.cfg["min_iters"], verbose=0)
-    _check_against_fixture(model, g, TOL_F64.get(name, TOL))
+    _check_against_fixture(model, g, TOL64)
 
 
 def test_fit_falls_back_to_level_sweeps_when_the_dataflow_launch_gives_up(monkeypatch):
