@@ -173,7 +173,7 @@ def cpu_baseline(eng, budget_s=20.0):
     V = eng.V[: eng.n, :k].double().cpu().numpy()
     b_i = eng.b_i[: eng.n].double().cpu().numpy()
     mu = float(eng.mu.item())
-    cap = 6_000_000
+    cap = 12_000_000          # ratings per sample: ~15-20 s of oracle time for both half-steps together
     # ---- users: a random sample, as a compact CSR over all items
     urows, uptr, uidx, uval = _sample_rows(eng.csr.indptr, eng.csr.indices, eng.csr.vals, eng.m, cap, 4001, eng.dev)
     su = urows.size

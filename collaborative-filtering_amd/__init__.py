@@ -13,7 +13,8 @@ from .helpers import (ES_MIN_ITERS, ES_TOL, DEFAULT_RANDOM_STATE, cholesky_solve
 
 from . import cv                     # sparse CV / ablation harness
 from . import features               # feature normaliser
+from . import sweep                  # resident-data hyper-parameter sweep driver
 
-__all__ = ["ALS", "cv", "features", "ALSConfig", "BiasesConfig", "CoreConfig", "GraphConfig", "GraphSimConfig",
+__all__ = ["ALS", "cv", "features", "sweep", "ALSConfig", "BiasesConfig", "CoreConfig", "GraphConfig", "GraphSimConfig",
            "cholesky_solve", "make_config", "normalize_params", "rmse_on_indices",
            "ES_TOL", "ES_MIN_ITERS", "DEFAULT_RANDOM_STATE"]

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libals_hip.so")
+# ALS_HIP_LIB: an alternative build of the library (profiling / A-B experiments: profiles/ab_builds.sh)
+LIB_PATH = os.environ.get("ALS_HIP_LIB") or os.path.join(_HERE, "csrc", "libals_hip.so")
 
 SPLIT_CHUNK = 4096          # ALS_SPLIT_CHUNK
 MAX_K = 160                 # ALS_MAX_K

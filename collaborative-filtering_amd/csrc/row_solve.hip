@@ -107,6 +107,36 @@ __device__ __forceinline__ int pack_hi16(float hi_src, float lo_src) {     // {h
     return __builtin_amdgcn_perm(__float_as_int(hi_src), __float_as_int(lo_src), 0x07060302);
 }
 
+// exact 3-way bf16 split of two floats (see process_chunk_bf16x3): packed high halves of x, of r = x - h and of
+// l = r - m.  With ALS_SPLIT_DOT2C the remainders come from v_dot2c_f32_bf16 on the packed word itself,
+//   r0 = x0 + (-1) * H.lo + 0 * H.hi,   r1 = x1 + 0 * H.lo + (-1) * H.hi
+// (one instruction per element instead of v_and + v_sub; the result is exactly representable, so the dot
+// unit's rounding cannot matter - profiles/ubench/split_dot2c.hip checks bit-identity on the hardware).
+#ifndef ALS_SPLIT_DOT2C
+#define ALS_SPLIT_DOT2C 0
+#endif
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3(float x0, float x1, int& H, int& M, int& L) {
+    H = pack_hi16(x1, x0);
+#if ALS_SPLIT_DOT2C
+    const bf16x2_t neg_lo = __builtin_bit_cast(bf16x2_t, 0x0000BF80), neg_hi = __builtin_bit_cast(bf16x2_t, (int)0xBF800000);
+    const float r0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, H), neg_lo, x0, false);
+    const float r1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, H), neg_hi, x1, false);
+    M = pack_hi16(r1, r0);
+    const float l0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, M), neg_lo, r0, false);
+    const float l1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, M), neg_hi, r1, false);
+#else
+    const float h0 = __int_as_float(__float_as_int(x0) & 0xFFFF0000);
+    const float h1 = __int_as_float(__float_as_int(x1) & 0xFFFF0000);
+    const float r0 = x0 - h0, r1 = x1 - h1;                       // exact
+    M = pack_hi16(r1, r0);
+    const float m0 = __int_as_float(__float_as_int(r0) & 0xFFFF0000);
+    const float m1 = __int_as_float(__float_as_int(r1) & 0xFFFF0000);
+    const float l0 = r0 - m0, l1 = r1 - m1;                       // exact, <= 8 significant bits
+#endif
+    L = pack_hi16(l1, l0);
+}
+
 template <int KB, bool FULL>
 __device__ __forceinline__ void process_chunk_bf16x3(RowAcc<KB>& A, int off_l, float r_l, int nvalid,
                                                      const float* __restrict__ Fc, int q) {
@@ -132,15 +162,9 @@ __device__ __forceinline__ void process_chunk_bf16x3(RowAcc<KB>& A, int off_l, f
                 A.rhs[b] = fmaf(x0, r_t[j], A.rhs[b]);
                 A.rhs[b] = fmaf(x1, r_t[j + 1], A.rhs[b]);
                 A.cs[b] += x0 + x1;
-                const float h0 = __int_as_float(__float_as_int(x0) & 0xFFFF0000);
-                const float h1 = __int_as_float(__float_as_int(x1) & 0xFFFF0000);
-                const float r0 = x0 - h0, r1 = x1 - h1;                       // exact
-                const float m0 = __int_as_float(__float_as_int(r0) & 0xFFFF0000);
-                const float m1 = __int_as_float(__float_as_int(r1) & 0xFFFF0000);
-                const float l0 = r0 - m0, l1 = r1 - m1;                       // exact, <= 8 significant bits
-                H[b][j >> 1] = pack_hi16(x1, x0);
-                M[b][j >> 1] = pack_hi16(r1, r0);
-                L[b][j >> 1] = pack_hi16(l1, l0);
+                int hw, mw, lw;
+                split3(x0, x1, hw, mw, lw);
+                H[b][j >> 1] = hw; M[b][j >> 1] = mw; L[b][j >> 1] = lw;
             }
         }
 #pragma unroll
@@ -736,16 +760,9 @@ __device__ __forceinline__ void row_dual(const als_row_solve_params& P, int row,
             }
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
-                const float x0 = f[e], x1 = f[e + 1];
-                const float h0 = __int_as_float(__float_as_int(x0) & 0xFFFF0000);
-                const float h1 = __int_as_float(__float_as_int(x1) & 0xFFFF0000);
-                const float r0 = x0 - h0, r1 = x1 - h1;                       // exact
-                const float m0 = __int_as_float(__float_as_int(r0) & 0xFFFF0000);
-                const float m1 = __int_as_float(__float_as_int(r1) & 0xFFFF0000);
-                const float l0 = r0 - m0, l1 = r1 - m1;                       // exact, <= 8 significant bits
-                H[I][e >> 1] = pack_hi16(x1, x0);
-                M[I][e >> 1] = pack_hi16(r1, r0);
-                L[I][e >> 1] = pack_hi16(l1, l0);
+                int hw, mw, lw;
+                split3(f[e], f[e + 1], hw, mw, lw);
+                H[I][e >> 1] = hw; M[I][e >> 1] = mw; L[I][e >> 1] = lw;
             }
         }
 #pragma unroll

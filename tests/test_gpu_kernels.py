@@ -88,9 +88,9 @@ def test_row_solve_against_numpy(k, gram):
         idx = side.indices[lo:hi]
         Fr = F32[idx]
         vals = side.vals[lo:hi].astype(np.float64)
-        rr = vals - (mu + np.float32(b_self[r]) + b_other.astype(np.float32)[idx])
+        rr = vals - (mu + float(np.float32(b_self[r])) + b_other.astype(np.float32)[idx].astype(np.float64))
         A = Fr.T @ Fr + (float(np.float32(lam_row[r])) + 1e-10 + float(np.float32(diag_extra[r]))) * np.eye(k)
-        b = Fr.T @ rr + rhs_extra.astype(np.float32)[r]
+        b = Fr.T @ rr + rhs_extra.astype(np.float32)[r].astype(np.float64)
         x = np.linalg.solve(A, b)
         scale = max(np.max(np.abs(x)), 1e-6)
         np.testing.assert_allclose(X[r, :k], x, rtol=xr, atol=xa * scale, err_msg=f"row {r} nnz {hi - lo}")

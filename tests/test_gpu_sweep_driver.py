@@ -1,0 +1,101 @@
+"""the resident-data sweep driver against the per-fit harness.
+
+`sweep.SweepDriver` uploads ratings / features once, cuts the K train matrices out of the resident CSR / CSC on
+the device and shares task lists, graphs, schedules and initial factors across fits; every fold score must be
+IDENTICAL to `cv.eval_variant_cv` (which rebuilds everything per fit through fit_coo + predict_at), since the
+train entries, their order and the kernels are the same."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from collaborative_filtering_amd import cv, sweep
+from tests.common import Golden
+
+PARAMS = [
+    {"n_factors": 8, "n_iters": 12, "lambda_u": 2.0, "lambda_v": 3.0, "lambda_bu": 1.5, "lambda_bi": 2.5,
+     "pop_reg_mode": "inverse_sqrt", "update_w_every": 2, "alpha": 0.0, "graph_feature": "__none__", "S_topk": 10,
+     "lambda_w_genres": 5.0, "lambda_w_years": 0.0},
+    {"n_factors": 8, "n_iters": 12, "lambda_u": 2.0, "lambda_v": 3.0, "lambda_bu": 1.5, "lambda_bi": 2.5,
+     "pop_reg_mode": None, "update_w_every": 3, "alpha": 0.5, "graph_feature": "genres", "S_topk": 10, "S_eps": 1e-8,
+     "lambda_w_genres": 5.0, "lambda_w_years": 10.0},
+    {"n_factors": 24, "n_iters": 14, "lambda_u": 4.0, "lambda_v": 1.0, "lambda_bu": 3.0, "lambda_bi": 2.0,
+     "pop_reg_mode": "inverse_sqrt", "update_w_every": 5, "alpha": 2.0, "graph_feature": "genres", "S_topk": 25,
+     "S_eps": 1e-8, "lambda_w_genres": 1.0, "lambda_w_years": 4.0},
+    {"n_factors": 80, "n_iters": 11, "lambda_u": 6.0, "lambda_v": 5.0, "lambda_bu": 3.0, "lambda_bi": 2.0,
+     "pop_reg_mode": None, "update_w_every": 4, "alpha": 0.0, "graph_feature": "__none__", "S_topk": 10,
+     "lambda_w_genres": 0.0, "lambda_w_years": 0.0},
+]
+
+
+def _setup():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected (-m gpu) but no ROCm device is visible")
+    g = Golden("g4_feat_uw2")
+    ratings = cv.CooRatings(g.rows, g.cols, g.vals, (g.m, g.n))
+    folds = cv.make_entrywise_folds(ratings, n_splits=3, seed=42)
+    return g, ratings, folds
+
+
+def test_fold_scores_identical_to_the_per_fit_harness(tmp_path):
+    g, ratings, folds = _setup()
+    drv = sweep.SweepDriver(ratings, g.features, folds)
+    item_bin, _ = cv.popularity_bins(np.bincount(ratings.cols, minlength=g.n), 3)
+    # the resident train matrices equal what fit_coo builds from the host split
+    from collaborative_filtering_amd import layout
+    for k, f in enumerate(drv.folds):
+        (tr, tc, tv), _, _ = cv.train_valid_split(ratings, folds, k)
+        csr, csc = layout.coo_to_sides(tr, tc, tv, ratings.shape)
+        for dev_side, host_side in ((f.csr, csr), (f.csc, csc)):
+            np.testing.assert_array_equal(dev_side.indptr.cpu().numpy(), host_side.indptr)
+            np.testing.assert_array_equal(dev_side.indices.cpu().numpy(), host_side.indices)
+            np.testing.assert_array_equal(dev_side.vals.cpu().numpy(), host_side.vals)
+    res = drv.run([dict(p) for p in PARAMS], out_dir=str(tmp_path), study_name="t")
+    assert res["n_trials"] == len(PARAMS) and res["fits"] == 3 * len(PARAMS)
+    for p, t in zip(PARAMS, res["trials"]):
+        f_rmse, _, _, f_iters = cv.eval_variant_cv("x", ratings, g.features, folds, dict(p), item_bin, 3,
+                                                   cv.ES_TOL, cv.ES_MIN_ITERS, {})
+        assert t["fold_rmse"] == f_rmse, (t["fold_rmse"], f_rmse)             # bitwise: same entries, same kernels
+        assert t["iters_per_fold"] == f_iters
+        assert t["value"] == float(np.mean(f_rmse))
+        assert t["early_stopped_folds"] == sum(i < p["n_iters"] for i in f_iters)
+    # every fold cache was hit (schedules, tasks, graph, initial factors are reused across trials)
+    assert all(f.cache.hits > 0 for f in drv.folds)
+    # artifacts in the reference's layout; best-params JSON is what cv.run_ablation reads
+    tdir = tmp_path / "tuning"
+    assert os.path.exists(tdir / "t_trials.csv")
+    best = json.loads((tdir / "t_best_params.json").read_text())
+    assert best["value"] == min(t["value"] for t in res["trials"]) and "n_factors" in best["params"]
+    summ = json.loads((tdir / "t_summary.json").read_text())
+    assert summ["matrix_shape"] == [g.m, g.n] and summ["n_complete"] == len(PARAMS) and summ["fits_per_second"] > 0
+
+
+def test_trial_protocol_reporting_and_pruning():
+    g, ratings, folds = _setup()
+    drv = sweep.SweepDriver(ratings, g.features, folds)
+
+    class Trial:
+        def __init__(self, prune_at):
+            self.prune_at, self.reports, self.attrs = prune_at, [], {}
+
+        def report(self, value, step):
+            self.reports.append((step, value))
+
+        def should_prune(self):
+            return len(self.reports) > self.prune_at
+
+        def set_user_attr(self, k, v):
+            self.attrs[k] = v
+
+    t = Trial(prune_at=99)
+    out = drv.cv_score(dict(PARAMS[0]), trial=t)
+    assert [s for s, _ in t.reports] == [0, 1, 2] and [v for _, v in t.reports] == out["fold_rmse"]
+    assert t.attrs["fold_rmse"] == out["fold_rmse"] and t.attrs["es_tol"] == cv.ES_TOL
+    t2 = Trial(prune_at=0)
+    with pytest.raises(sweep.SweepPruned):
+        drv.cv_score(dict(PARAMS[0]), trial=t2)
+    assert len(t2.reports) == 1
