@@ -145,6 +145,21 @@ def _on(device):
     return torch.cuda.device(device) if device.type == "cuda" else contextlib.nullcontext()
 
 
+class _RowShift:
+    """A by-product array that exists for the rank's own rows [row0, row0 + rows) only, addressed by the kernels
+    with ABSOLUTE row ids: data_ptr() is moved back by row0 rows (never dereferenced outside the local rows; the
+    C ABI takes plain pointers).  Everything else is the underlying tensor's."""
+
+    def __init__(self, t: torch.Tensor, row0: int, row_elems: int):
+        self.t, self.row0, self.row_elems = t, int(row0), int(row_elems)
+
+    def data_ptr(self) -> int:
+        return self.t.data_ptr() - self.row0 * self.row_elems * self.t.element_size()
+
+    def __getattr__(self, name):
+        return getattr(self.t, name)
+
+
 def _to_dev(a, device, dtype) -> torch.Tensor:
     if isinstance(a, torch.Tensor):
         return a.to(device=device, dtype=dtype).contiguous()
@@ -385,10 +400,14 @@ class ALS:
 class _Engine:
     """Device state and the iteration loop of one `fit`."""
 
-    U_CHUNKS = 4        # sub-ranges of a rank's user shard (multi-rank runs only)
+    U_CHUNKS = 2        # sub-ranges of a rank's user shard (multi-rank runs only; ALS_U_CHUNKS overrides)
 
     def __init__(self, model: ALS, csr, csc, features, S_csr, device, backend, pg, gs_mode):
-        self.model = model
+        import weakref
+        # no reference cycle with the model (which owns this engine): both then die by reference count, at a
+        # deterministic point - a cyclic-GC pass destroying captured HIP graphs in the middle of ANOTHER engine's
+        # stream capture is an error ("operation not permitted when stream is capturing")
+        self.model = weakref.proxy(model)
         self.dev = device
         self.be = backend
         # sharding is opt-in: process_group="world" (the default group) or a ProcessGroup object; None fits on
@@ -420,16 +439,6 @@ class _Engine:
         self.perm = torch.from_numpy(layout.perm_of_col(k)).to(device)     # storage col -> perm pos
         f32, f64 = torch.float32, torch.float64
 
-        # --- shards (contiguous, equal row counts; storage padded to world * per)
-        # the user shard is solved in U_CHUNKS sub-ranges whose all-gathers overlap the next sub-range's solve
-        self.u_chunks = self.U_CHUNKS if self.multi else 1
-        self.u_per, ub = layout.shard_bounds(self.m, self.world, self.u_chunks)
-        self.i_per, ib = layout.shard_bounds(self.n, self.world)
-        self.ub, self.ue = ub[self.rank]
-        self.ib, self.ie = ib[self.rank]
-        m_pad, n_pad = self.u_per * self.world, self.i_per * self.world
-        self.m_pad, self.n_pad = m_pad, n_pad
-
         cache = model._fit_cache if model._fit_cache is not None else _NoCache()
         ku, ki = cache.pin(csr), cache.pin(csc)
 
@@ -438,6 +447,17 @@ class _Engine:
         self.csc = cache.get(("side_dev", ki), lambda: _side_to_dev(csc, device))
         uptr_h = cache.get(("indptr_h", ku), lambda: self.csr.indptr.cpu().numpy())
         iptr_h = cache.get(("indptr_h", ki), lambda: self.csc.indptr.cpu().numpy())
+
+        # --- shards: contiguous row ranges balanced by number of ratings; every rank derives the same
+        # tables from the row pointers.  The user shard is solved in u_chunks sub-ranges whose all-gathers overlap
+        # the next sub-range's solve.  Factor storage is exactly [rows + 1, ld] (the extra row is the zero row).
+        self.u_chunks = max(1, int(os.environ.get("ALS_U_CHUNKS", self.U_CHUNKS))) if self.multi else 1
+        self.ubounds, self.uchunks = layout.shard_bounds_nnz(uptr_h, self.world, self.u_chunks)
+        self.ibounds, _ = layout.shard_bounds_nnz(iptr_h, self.world)
+        self.ub, self.ue = self.ubounds[self.rank]
+        self.ib, self.ie = self.ibounds[self.rank]
+        m_pad, n_pad = self.m, self.n
+        self.m_pad, self.n_pad = m_pad, n_pad
         dl = layout.dual_max_len(k)          # rows this short are solved in the dual form (k_row_dual)
         dm = layout.dual_mid_len(k)          # ... and rows up to this length above k = 96 (k_row_dual_mid)
         lib = getattr(backend, "lib", None)  # HIP backend: set-up passes in the library (csrc/host_setup.cpp)
@@ -453,12 +473,7 @@ class _Engine:
         self.utasks = tasks_dev(ku, uptr_h, self.ub, self.ue)
         self.itasks = tasks_dev(ki, iptr_h, self.ib, self.ie)
         if self.u_chunks > 1:
-            sub = self.u_per // self.u_chunks
-            lo0 = self.rank * self.u_per
-            self.utasks_c = [tasks_dev(ku, uptr_h, min(lo0 + c * sub, self.m), min(lo0 + (c + 1) * sub, self.m))
-                             for c in range(self.u_chunks)]
-            self.u_stage = torch.empty(self.u_chunks, self.world, sub, self.ld, dtype=torch.float32, device=device)
-            self.bu_stage = torch.empty(self.u_chunks, self.world, sub, dtype=torch.float32, device=device)
+            self.utasks_c = [tasks_dev(ku, uptr_h, b, e) for b, e in self.uchunks[self.rank]]
         nslots = max(self.utasks.nslots, self.itasks.nslots)
         self.workspace = (torch.empty(nslots * backend.slot_bytes(k) // 4, dtype=f32, device=device)
                           if nslots else None)
@@ -572,13 +587,24 @@ class _Engine:
                 self.S_idx_wait = wait_dev
                 self.gs_publish = torch.empty(n_pad, self.ld, dtype=f32, device=device)       # same shape as V
                 self.gs_err = torch.zeros(1, dtype=torch.int32, device=device)
-            self.factor = torch.zeros(n_pad * self.ld * self.ld, dtype=f32, device=device)
-            self.sumr = torch.zeros(n_pad, dtype=f32, device=device)
+        # By-products of the V-step exist for this rank's items only ([ib, ie): n / world rows instead of n - the
+        # item Grams and Cholesky factors are n * ld^2 floats each, 65 GB at BASELINE configs[4]); the kernels index
+        # them with absolute item ids through a shifted base pointer (_RowShift).  The numpy stand-in of the CPU
+        # tests indexes tensors directly, so it keeps full-size arrays.
+        self.local_rows = (self.ib, self.ie - self.ib) if lib is not None else (0, n_pad)
+        r0, nloc = self.local_rows
+
+        def local(*row_shape):
+            t = torch.zeros((nloc,) + row_shape, dtype=f32, device=device)
+            return _RowShift(t, r0, int(np.prod(row_shape)) if row_shape else 1) if lib is not None else t
+
+        if self.use_graph:
+            self.factor = local(self.ld * self.ld)
+            self.sumr = local()
         need_byproducts = self.use_graph or bool(self.feat_names)
-        self.rhs_out = torch.zeros(n_pad, self.ld, dtype=f32, device=device) if need_byproducts else None
-        self.colsum_out = torch.zeros(n_pad, self.ld, dtype=f32, device=device) if need_byproducts else None
-        self.gram = (torch.zeros(n_pad, self.ld, self.ld, dtype=f32, device=device)
-                     if self.feat_names else None)
+        self.rhs_out = local(self.ld) if need_byproducts else None
+        self.colsum_out = local(self.ld) if need_byproducts else None
+        self.gram = local(self.ld, self.ld) if self.feat_names else None
 
         # --- fused statistics (DESIGN.md "Statistics"): without features Z == V, so the residual
         #     sums of an iteration follow in closed form from what the V-step already holds
@@ -589,13 +615,13 @@ class _Engine:
         self.fused_feat_stats = (bool(self.feat_names) and hasattr(backend, "item_stats")
                                  and hasattr(backend, "sum_pairs"))
         if self.fused_stats or self.fused_feat_stats:
-            self.stat_rows = torch.zeros(n_pad, 2, dtype=f32, device=device)
+            self.stat_rows = local(2)
             if self.use_graph or self.fused_feat_stats:
-                self.sumr2 = torch.zeros(n_pad, dtype=f32, device=device)
+                self.sumr2 = local()
             if self.use_graph:
                 self.lam_eff = (self.lam_v_row + np.float32(EPS) + self.diag_extra).contiguous()
         if self.fused_feat_stats and not self.use_graph:
-            self.sumr = torch.zeros(n_pad, dtype=f32, device=device)
+            self.sumr = local()
         # --- stats scratch
         self.stats = torch.zeros(2, dtype=f64, device=device)
         self.ss = torch.zeros(4, dtype=f64, device=device)
@@ -618,12 +644,31 @@ class _Engine:
             self.Wcat[off:off + d, : self.k] = self.W64[f].to(torch.float32)
             off += d
 
-    def _allgather_rows(self, t: torch.Tensor, per: int):
-        """In-place all-gather of equal contiguous row shards of `t`."""
+    def _allgather_rows(self, t: torch.Tensor, bounds, async_op: bool = False):
+        """All-gather of the contiguous, unevenly sized row shards `bounds[r] = (begin, end)` of `t`: every rank
+        contributes its rows padded to the longest shard (one all_gather_into_tensor - RCCL and gloo both need
+        equal sizes), `finish()` copies the other ranks' rows into place.  Returns finish (called at once unless
+        async_op)."""
         if not self.multi:
-            return
-        mine = t[self.rank * per:(self.rank + 1) * per].clone()
-        dist.all_gather_into_tensor(t.view(-1), mine.view(-1), group=self.pg)
+            return None
+        b, e = bounds[self.rank]
+        per = max(max(hi - lo for lo, hi in bounds), 1)
+        tail = tuple(t.shape[1:])
+        mine = torch.zeros((per,) + tail, dtype=t.dtype, device=t.device)
+        mine[: e - b] = t[b:e]
+        stage = torch.empty((self.world, per) + tail, dtype=t.dtype, device=t.device)
+        work = dist.all_gather_into_tensor(stage.view(-1), mine.view(-1), group=self.pg, async_op=async_op)
+
+        def finish():
+            if work is not None:
+                work.wait()
+            for r, (lo, hi) in enumerate(bounds):
+                if r != self.rank and hi > lo:
+                    t[lo:hi] = stage[r, : hi - lo]
+        if async_op:
+            return finish
+        finish()
+        return None
 
     def _global_rank(self, r: int) -> int:
         return r if self.pg is None else dist.get_global_rank(self.pg, r)
@@ -677,26 +722,20 @@ class _Engine:
         if self.u_chunks == 1:
             with self._tick("row_solve_user"):
                 self.be.row_solve(tasks=self.utasks, **kw)
-            self._allgather_rows(self.U, self.u_per)
-            self._allgather_rows(self.b_u, self.u_per)
+            self._allgather_rows(self.U, self.ubounds)
+            self._allgather_rows(self.b_u, self.ubounds)
             return
-        C, sub, lo0 = self.u_chunks, self.u_per // self.u_chunks, self.rank * self.u_per
-        works = []
+        pending = []
         with self._tick("row_solve_user"):
-            for c in range(C):
+            for c in range(self.u_chunks):
                 if self.utasks_c[c].ntasks or self.utasks_c[c].nlong:
                     self.be.row_solve(tasks=self.utasks_c[c], **kw)
-                rows = slice(lo0 + c * sub, lo0 + (c + 1) * sub)
-                works.append(dist.all_gather_into_tensor(self.u_stage[c].view(-1), self.U[rows].reshape(-1),
-                                                         group=self.pg, async_op=True))
-                works.append(dist.all_gather_into_tensor(self.bu_stage[c].view(-1), self.b_u[rows].reshape(-1),
-                                                         group=self.pg, async_op=True))
+                cb = [self.uchunks[r][c] for r in range(self.world)]        # sub-range c of every rank's shard
+                pending.append(self._allgather_rows(self.U, cb, async_op=True))
+                pending.append(self._allgather_rows(self.b_u, cb, async_op=True))
         with self._tick("allgather_user_wait"):
-            for w in works:
-                w.wait()
-            # stage[c][g] holds rows [g*per + c*sub, +sub) of rank g
-            self.U.view(self.world, C, sub, self.ld).copy_(self.u_stage.transpose(0, 1))
-            self.b_u.view(self.world, C, sub).copy_(self.bu_stage.transpose(0, 1))
+            for finish in pending:
+                finish()
 
     def item_step(self, want_gram: bool):
         """scripts/als.py:436-466 on this rank's item shard, then all-gather.
@@ -734,14 +773,15 @@ class _Engine:
                     for r in range(self.world):
                         if r == self.rank:
                             self._gs_sweep()
-                        dist.broadcast(self.V[r * self.i_per:(r + 1) * self.i_per], src=self._global_rank(r),
-                                       group=self.pg)
-                self._allgather_rows(self.b_i, self.i_per)
+                        lo, hi = self.ibounds[r]
+                        if hi > lo:
+                            dist.broadcast(self.V[lo:hi], src=self._global_rank(r), group=self.pg)
+                self._allgather_rows(self.b_i, self.ibounds)
                 return
             with self._tick("gs_sweep"):
                 self._gs_sweep()
-        self._allgather_rows(self.V, self.i_per)
-        self._allgather_rows(self.b_i, self.i_per)
+        self._allgather_rows(self.V, self.ibounds)
+        self._allgather_rows(self.b_i, self.ibounds)
 
     def _gs_sweep(self):
         md = self.model
@@ -777,7 +817,8 @@ class _Engine:
 
     def _exchange_level(self, items: torch.Tensor, it_np: np.ndarray):
         """Exact multi-GPU sweep: publish this level's freshly solved V rows."""
-        owner = np.minimum(it_np // self.i_per, self.world - 1)
+        ends = np.array([hi for _, hi in self.ibounds], dtype=np.int64)
+        owner = np.searchsorted(ends, it_np, side="right")          # rank whose [begin, end) holds the item
         cnt = np.bincount(owner, minlength=self.world)
         cmax = int(cnt.max())
         if cmax == 0:
@@ -814,7 +855,9 @@ class _Engine:
         md = self.model
         k, ld = self.k, self.ld
         if not hasattr(self, "H"):
-            self.H = torch.zeros(len(self.feat_names), self.n_pad, ld, dtype=torch.float32, device=self.dev)
+            r0, nloc = self.local_rows
+            H = torch.zeros(len(self.feat_names), nloc, ld, dtype=torch.float32, device=self.dev)
+            self.H = _RowShift(H, r0, ld) if r0 or nloc != self.n_pad else H
             offs = np.concatenate([[0], np.cumsum(self.feat_dims)]).astype(np.int32)
             self.feat_off_host = offs
             self.feat_off = torch.from_numpy(offs).to(self.dev)
@@ -925,6 +968,7 @@ class _Engine:
                             logger.info("Early stopping at iter %d; dRMSE <= %.3g", it + 1, tol)
                         break
         self._check_status()
+        self._graphs.clear()            # captured iteration graphs are not needed past the fit
 
     # --------------------------------------------------------------- export
     def export(self, model: ALS):

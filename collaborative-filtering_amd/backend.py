@@ -195,6 +195,7 @@ class HipBackend:
 
     def sum_pairs(self, x: torch.Tensor, out: torch.Tensor):
         """out[0:2] = column sums of x viewed as [n, 2] (fp64, deterministic)."""
+        x = getattr(x, "t", x)              # a rank-local by-product array (als._RowShift): reduce what exists
         part = torch.empty(2 * self._sumsq_partials.numel(), dtype=torch.float64, device=self.device)
         self._check(self.lib.als_sum_pairs(_p(x), x.numel() // 2, _p(part), _p(out), self._stream()),
                     "als_sum_pairs")

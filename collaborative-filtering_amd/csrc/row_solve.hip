@@ -108,24 +108,11 @@ __device__ __forceinline__ int pack_hi16(float hi_src, float lo_src) {     // {h
 }
 
 // exact 3-way bf16 split of two floats (see process_chunk_bf16x3): packed high halves of x, of r = x - h and of
-// l = r - m.  With ALS_SPLIT_DOT2C the remainders come from v_dot2c_f32_bf16 on the packed word itself,
-//   r0 = x0 + (-1) * H.lo + 0 * H.hi,   r1 = x1 + 0 * H.lo + (-1) * H.hi
-// (one instruction per element instead of v_and + v_sub; the result is exactly representable, so the dot
-// unit's rounding cannot matter - profiles/ubench/split_dot2c.hip checks bit-identity on the hardware).
-#ifndef ALS_SPLIT_DOT2C
-#define ALS_SPLIT_DOT2C 0
-#endif
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// l = r - m.  (v_dot2c_f32_bf16 with a (-1, 0) constant on the packed word would form a remainder in one
+// instruction instead of v_and + v_sub; on gfx950 it did NOT reproduce the remainders bit for bit and issues at
+// half rate with three waves per SIMD - profiles/ubench/split_dot2c.hip, profiles/r02_ubench_split_dot2c.txt.)
 __device__ __forceinline__ void split3(float x0, float x1, int& H, int& M, int& L) {
     H = pack_hi16(x1, x0);
-#if ALS_SPLIT_DOT2C
-    const bf16x2_t neg_lo = __builtin_bit_cast(bf16x2_t, 0x0000BF80), neg_hi = __builtin_bit_cast(bf16x2_t, (int)0xBF800000);
-    const float r0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, H), neg_lo, x0, false);
-    const float r1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, H), neg_hi, x1, false);
-    M = pack_hi16(r1, r0);
-    const float l0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, M), neg_lo, r0, false);
-    const float l1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, M), neg_hi, r1, false);
-#else
     const float h0 = __int_as_float(__float_as_int(x0) & 0xFFFF0000);
     const float h1 = __int_as_float(__float_as_int(x1) & 0xFFFF0000);
     const float r0 = x0 - h0, r1 = x1 - h1;                       // exact
@@ -133,7 +120,6 @@ __device__ __forceinline__ void split3(float x0, float x1, int& H, int& M, int& 
     const float m0 = __int_as_float(__float_as_int(r0) & 0xFFFF0000);
     const float m1 = __int_as_float(__float_as_int(r1) & 0xFFFF0000);
     const float l0 = r0 - m0, l1 = r1 - m1;                       // exact, <= 8 significant bits
-#endif
     L = pack_hi16(l1, l0);
 }
 

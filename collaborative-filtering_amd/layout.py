@@ -171,6 +171,34 @@ def shard_bounds(nrows: int, world: int, multiple: int = 1) -> Tuple[int, List[T
     return per, [(min(r * per, nrows), min((r + 1) * per, nrows)) for r in range(world)]
 
 
+def shard_bounds_nnz(indptr: np.ndarray, world: int, chunks: int = 1):
+    """Contiguous row shards balanced by number of ratings: shard r ends at the first row
+    where the running count reaches (r + 1) / world of the total.  Returns ([(begin, end)] per rank,
+    [[(begin, end)] * chunks per rank]): every shard is cut the same way into `chunks` sub-ranges (the U-step
+    solves and all-gathers them one after the other).  Deterministic from `indptr` alone, so every rank computes
+    the same tables.  Row counts differ between shards; empty shards are possible (world > rows)."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    nrows = len(indptr) - 1
+    total = int(indptr[-1])
+
+    def cut(lo: int, hi: int, parts: int):
+        n_lo, n_hi = int(indptr[lo]), int(indptr[hi])
+        edges = [lo]
+        for j in range(1, parts):
+            target = n_lo + (n_hi - n_lo) * j / parts
+            e = int(np.searchsorted(indptr, target, side="left"))
+            edges.append(min(max(e, edges[-1]), hi))
+        edges.append(hi)
+        return [(edges[j], edges[j + 1]) for j in range(parts)]
+
+    if total == 0:                                   # nothing to balance: equal row counts
+        per = -(-nrows // world)
+        bounds = [(min(r * per, nrows), min((r + 1) * per, nrows)) for r in range(world)]
+    else:
+        bounds = cut(0, nrows, world)
+    return bounds, [cut(b, e, chunks) for b, e in bounds]
+
+
 def build_similarity_dense(X: np.ndarray, topk: Optional[int], eps: float) -> np.ndarray:
     """Item-item cosine top-k graph, symmetrised by max.
 

@@ -118,13 +118,75 @@ def test_block_gauss_seidel_is_close_and_consistent():
 
 
 def test_three_ranks_uneven_shards():
-    """world_size 3 on 300 x 200: shard sizes do not divide evenly (padding rows of the last rank)."""
+    """world_size 3 on 300 x 200: three rating-balanced shards of different row counts."""
     g, ref = _single("g2_bias_pop")
     outs = _run("g2_bias_pop", world=3)
     for r in (1, 2):
         np.testing.assert_array_equal(outs[0]["U"], outs[r]["U"])
     np.testing.assert_array_equal(outs[0]["U"], ref.U)
     np.testing.assert_array_equal(outs[0]["V"], ref.V)
+
+
+def _skewed_problem():
+    """120 x 90 with heavy rows FIRST (ids sorted by descending count): equal-row shards would be badly
+    unbalanced, rating-balanced shards have very different row counts (some ranks own a handful of rows)."""
+    from collaborative_filtering_amd import layout
+    from tests.synth import make_features, make_ratings
+    m, n = 120, 90
+    r, c, v = make_ratings(m, n, 2600, seed=77, user_exp=1.5, item_exp=1.3)
+    ur = np.argsort(np.argsort(-np.bincount(r, minlength=m), kind="stable"), kind="stable")
+    ir = np.argsort(np.argsort(-np.bincount(c, minlength=n), kind="stable"), kind="stable")
+    r, c = ur[r], ir[c]
+    o = np.lexsort((c, r))
+    G, _ = make_features(n, 5)
+    S = layout.dense_graph_to_csr(layout.build_similarity_dense(G, 6, 1e-8))
+    return (r[o], c[o], v[o]), (m, n), (S[0], S[1].astype(np.int64), S[2])
+
+
+def _skewed_worker(rank, world, port, graph, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from collaborative_filtering_amd import ALS, ALSConfig, BiasesConfig, CoreConfig, GraphConfig, GraphSimConfig
+        from tests.cpu_backend import NumpyBackend
+        (r, c, v), shape, S = _skewed_problem()
+        cfg = ALSConfig(core=CoreConfig(n_factors=6, n_iters=4, lambda_u=2.0, lambda_v=3.0, pop_reg_mode="inverse_sqrt"),
+                        biases=BiasesConfig(1.5, 2.5),
+                        graph=GraphConfig(alpha=0.7, sim=GraphSimConfig(source="precomputed")) if graph else GraphConfig())
+        model = ALS(cfg, device="cpu", backend=NumpyBackend(), process_group="world" if world > 1 else None)
+        model.fit_coo(r, c, v, shape, tol=None, verbose=0, S=S if graph else None)
+        eng = model._eng
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), U=model.U, V=model.V, b_u=model.b_u, b_i=model.b_i,
+                 mu=model.mu, rmse=np.asarray(model.history["train_rmse"]),
+                 ubounds=np.asarray(eng.ubounds), ibounds=np.asarray(eng.ibounds))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_four_ranks_rating_balanced_shards_on_a_skewed_input(graph):
+    """world_size 4, shards balanced by number of ratings on an input whose heavy rows are
+    contiguous: row counts per shard differ by an order of magnitude, the all-gathers are uneven, and with the
+    Laplacian the exact sweep goes shard by shard.  Still bitwise the one-rank fit."""
+    with tempfile.TemporaryDirectory() as d1, tempfile.TemporaryDirectory() as d4:
+        _skewed_worker(0, 1, 0, graph, d1)
+        ref = np.load(os.path.join(d1, "rank0.npz"))
+        mp.spawn(_skewed_worker, args=(4, _free_port(), graph, d4), nprocs=4, join=True)
+        outs = [np.load(os.path.join(d4, f"rank{r}.npz")) for r in range(4)]
+    ub = outs[0]["ubounds"]
+    rows = ub[:, 1] - ub[:, 0]
+    assert rows.sum() == 120 and rows.max() >= 4 * max(rows.min(), 1), rows        # genuinely uneven shards
+    (r, c, v), _, _ = _skewed_problem()
+    per = np.array([np.sum((r >= b) & (r < e)) for b, e in ub])
+    assert per.max() <= 1.5 * per.mean() + np.bincount(r).max(), per             # balanced up to one heavy row
+    for o in outs:
+        for key in ("U", "V", "b_u", "b_i", "rmse"):
+            np.testing.assert_array_equal(o[key], ref[key], err_msg=key)
+        assert float(o["mu"]) == float(ref["mu"])
 
 
 def test_fused_statistics_closed_form_on_cpu():

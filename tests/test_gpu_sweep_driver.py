@@ -27,7 +27,7 @@ PARAMS = [
      "S_eps": 1e-8, "lambda_w_genres": 1.0, "lambda_w_years": 4.0},
     {"n_factors": 80, "n_iters": 11, "lambda_u": 6.0, "lambda_v": 5.0, "lambda_bu": 3.0, "lambda_bi": 2.0,
      "pop_reg_mode": None, "update_w_every": 4, "alpha": 0.0, "graph_feature": "__none__", "S_topk": 10,
-     "lambda_w_genres": 0.0, "lambda_w_years": 0.0},
+     "lambda_w_genres": 0.5, "lambda_w_years": 2.0},
 ]
 
 
