@@ -334,7 +334,9 @@ class ALS:
                 elif self._graph_build == "device":
                     dev = self._device or torch.device("cuda", torch.cuda.current_device())
                     with _on(dev):
-                        S_csr = layout.build_similarity_device(X, self.S_topk, self.S_eps, dev)
+                        from . import _hip
+                        S_csr = layout.build_similarity_device(X, self.S_topk, self.S_eps, dev,
+                                                               lib=_hip.load() if self._backend is None else None)
                     self.S = S_csr[:3]
                 else:
                     self.S, S_csr = _similarity_cached(X, self.S_topk, self.S_eps)
@@ -678,11 +680,13 @@ class _Engine:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
 
     def _check_status(self):
-        if getattr(self, "w_bad", None) is not None and int(self.w_bad.item()):
-            raise np.linalg.LinAlgError("W-step normal equations of a feature are not positive definite")
+        # the sweep's error word first: it is sticky, every later sweep bails out at its first wait, and whatever
+        # else went wrong afterwards (NaN factors -> "not positive definite") is a consequence
         if getattr(self, "gs_dataflow", False) and int(self.gs_err.item()):
             raise SweepNotResident("Gauss-Seidel dataflow sweep: a dependency wait exceeded its bound (the persistent "
                                    "launch was not resident as a whole)")
+        if getattr(self, "w_bad", None) is not None and int(self.w_bad.item()):
+            raise np.linalg.LinAlgError("W-step normal equations of a feature are not positive definite")
         bad = int(self.status.item())
         if bad:
             self.status.zero_()
@@ -877,7 +881,8 @@ class _Engine:
             x = self.be.spd_solve(A_full, B_full, float(md.lambda_w.get(f, 0.0)) + EPS, self.w_status)
             torch.maximum(self.w_bad, self.w_status, out=self.w_bad)     # no host round trip inside an iteration
             newW[f] = x.reshape(d, k)
-        self.W64.update(newW)
+        for f in self.feat_names:           # into the persistent buffers (Jacobi across features: all solves first);
+            self.W64[f].copy_(newW[f])      # a tensor born inside a captured iteration lives in the graph's pool
         self._sync_wcat()
 
     # ---------------------------------------------------------------- stats

@@ -218,10 +218,64 @@ def build_similarity_dense(X: np.ndarray, topk: Optional[int], eps: float) -> np
     return np.maximum(S, S.T)
 
 
-def build_similarity_device(X, topk: Optional[int], eps: float, device, block: int = 4096):
+def _graph_csr_from_coo(r, c, v, n, device):
+    """Sorted COO (unique entries) -> (ptr int64, idx int32, val float32, D float32); D = S.sum(axis=1) from an
+    fp64 prefix sum (deterministic)."""
+    import torch
+    order = torch.argsort(r * n + c)
+    r, c, v = r[order], c[order], v[order]
+    ptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    ptr[1:] = torch.cumsum(torch.bincount(r, minlength=n), 0)
+    csum = torch.zeros(v.numel() + 1, dtype=torch.float64, device=device)
+    csum[1:] = torch.cumsum(v.to(torch.float64), 0)
+    D = (csum[ptr[1:]] - csum[ptr[:-1]]).to(torch.float32)
+    return ptr, c.to(torch.int32), v.to(torch.float32), D
+
+
+TOPK_KERNEL_MAX_D = 64
+TOPK_KERNEL_MAX_K = 128      # ALS_TOPK_MAX
+
+
+def build_similarity_kernel(lib, X, topk: int, eps: float, device, stream=None):
+    """The graph of `build_similarity_dense` by the hand-written kernels of csrc/graph_build.hip (SURVEY section
+    8(f) n2): als_topk_similarity (cosine products on the fp32 matrix cores + per-row top-k under the total order
+    (similarity descending, index ascending)) and als_graph_classify (max-symmetrisation on the lists); the
+    surviving entries are sorted into CSR here.  fp32 throughout; d <= 64, topk <= 128, topk < n."""
+    import ctypes as C
+    import torch
+    Xd = torch.as_tensor(np.asarray(X, dtype=np.float32), device=device)
+    n, d = Xd.shape
+    Xn = Xd / (torch.sqrt((Xd * Xd).sum(1, keepdim=True)) + np.float32(eps))
+    ns = next(s for s in (1, 2, 4, 5, 8, 16) if 4 * s >= d)
+    n_pad = 16 * ((n + 15) // 16)
+    XT = torch.zeros(n_pad, 4 * ns, dtype=torch.float32, device=device)
+    XT[:n, :d] = Xn
+    XT = XT.view(n_pad, ns, 4).permute(1, 0, 2).contiguous()
+    tv = torch.empty(n, topk, dtype=torch.float32, device=device)
+    ti = torch.empty(n, topk, dtype=torch.int32, device=device)
+    tc = torch.empty(n, dtype=torch.int32, device=device)
+    own = torch.empty(n, topk, dtype=torch.uint8, device=device)
+    mir = torch.empty(n, topk, dtype=torch.uint8, device=device)
+    st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream if stream is None else stream)
+    p = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
+    rc = lib.als_topk_similarity(n, n_pad, ns, p(XT), int(topk), p(tv), p(ti), p(tc), st)
+    if rc == 0:
+        rc = lib.als_graph_classify(n, int(topk), p(tv), p(ti), p(tc), p(own), p(mir), st)
+    if rc != 0:
+        raise RuntimeError(f"graph build kernels failed with status {rc}")
+    rows = torch.arange(n, device=device)[:, None].expand(-1, topk)
+    o, mr = own.bool(), mir.bool()
+    r = torch.cat([rows[o], ti[mr].to(torch.int64)])
+    c = torch.cat([ti[o].to(torch.int64), rows[mr]])
+    v = torch.cat([tv[o], tv[mr]])
+    return _graph_csr_from_coo(r, c, v, n, device)
+
+
+def build_similarity_device(X, topk: Optional[int], eps: float, device, block: int = 4096, lib=None):
     """Device-side build of the same graph as `build_similarity_dense`, without the n x n matrix
-    (SURVEY section 8(f) n2): blocked cosine products, per-row top-k, symmetrised by max, returned as CSR
-    (ptr int64, idx int32, val float32, D float32) device tensors.
+    (SURVEY section 8(f) n2): cosine products, per-row top-k, symmetrised by max, returned as CSR
+    (ptr int64, idx int32, val float32, D float32) device tensors.  With the C-ABI library (`lib`) and
+    d <= 64, topk <= 128 < n this is `build_similarity_kernel`; otherwise the blocked torch formulation below.
 
     NOT tie-identical to the reference: among equal similarities at the top-k boundary numpy's
     `argpartition` (scripts/als.py:235) keeps an implementation-defined subset, here the lowest
@@ -230,6 +284,10 @@ def build_similarity_device(X, topk: Optional[int], eps: float, device, block: i
     stays the default because binary features (genres) tie massively.
     """
     import torch
+    Xshape = np.shape(X)
+    if (lib is not None and topk is not None and topk < Xshape[0] and topk <= TOPK_KERNEL_MAX_K
+            and Xshape[1] <= TOPK_KERNEL_MAX_D and torch.device(device).type == "cuda"):
+        return build_similarity_kernel(lib, X, topk, eps, device)
     Xd = torch.as_tensor(np.asarray(X), device=device)
     n = Xd.shape[0]
     Xn = Xd / (torch.sqrt((Xd * Xd).sum(1, keepdim=True)) + eps)

@@ -311,6 +311,24 @@ int als_predict_dense(int k, int ld, int64_t m, int64_t n, const float* U,
                       const double* mu, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Item-item similarity graph on the device (scripts/als.py:224-240 without the n x n matrix).
+ * als_topk_similarity: XT is the row-normalised feature matrix Xn [n][d] (fp32) re-laid as [nsteps][n_pad][4]
+ *   (feature dims in groups of 4, zero padded: nsteps in {1, 2, 4, 5, 8, 16}, i.e. d <= 64; n_pad a multiple of
+ *   16, padding rows zero).  For every row i the topk (<= ALS_TOPK_MAX) largest similarities <xn_i, xn_j>, j != i,
+ *   ordered by (similarity descending, j ascending) - among equal similarities the LOWEST column indices win (the
+ *   reference's argpartition keeps an implementation-defined subset of such ties):
+ *   top_val / top_idx [n][topk] (unused slots 0 / -1), top_cnt [n] = min(topk, n - 1).
+ * als_graph_classify: S = max(S, S^T) on those lists: own[i][t] = 1 when entry t of row i is an edge of the
+ *   symmetric graph, mirror[i][t] = 1 when its transpose (j, i, s) must be added because j's list does not
+ *   contain i (one-sided positive entries; one-sided negative ones and zeros are not edges).
+ * ------------------------------------------------------------------------- */
+#define ALS_TOPK_MAX 128
+int als_topk_similarity(int64_t n, int64_t n_pad, int nsteps, const float* XT, int topk, float* top_val,
+                        int32_t* top_idx, int32_t* top_cnt, void* stream);
+int als_graph_classify(int64_t n, int topk, const float* top_val, const int32_t* top_idx,
+                       const int32_t* top_cnt, uint8_t* own, uint8_t* mirror, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Host-side set-up passes (HOST pointers, synchronous, no GPU involved).  They replace the reference's
  * per-fit index-list construction (scripts/als.py:332-340) and prepare the inputs of the entry points above;
  * the named caller times fit + predict together (scripts/evaluate_models.py:245-255), so this is inside its

@@ -1,0 +1,101 @@
+"""the hand-written similarity-graph kernels (csrc/graph_build.hip: cosine products on the
+fp32 matrix cores + per-row top-k + max-symmetrisation) against the reference-style dense host build
+(layout.build_similarity_dense = scripts/als.py:224-240 call for call)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _env():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected (-m gpu) but no ROCm device is visible")
+    from collaborative_filtering_amd import _hip, layout
+    return torch, layout, _hip.load(), torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("n,d,topk", [(300, 7, 5), (300, 3, 128), (1000, 19, 50), (1537, 33, 40), (77, 64, 16), (40, 2, 39)])
+def test_kernel_graph_equals_dense_host_build_without_ties(n, d, topk):
+    """Continuous features: all similarities distinct, so the graph is unique - pattern identical, values to fp32
+    rounding (different summation order than numpy's matmul).  d = 3 / topk = 128 keeps negative similarities in
+    the lists (one-sided negative entries must vanish under max(S, S^T), mutual ones stay)."""
+    torch, layout, lib, dev = _env()
+    rng = np.random.default_rng(1000 * n + d)
+    X = rng.normal(size=(n, d)).astype(np.float32)
+    Sd = layout.build_similarity_dense(X.copy(), topk, 1e-8)
+    hp, hi, hv = layout.dense_graph_to_csr(Sd)
+    ptr, idx, val, D = layout.build_similarity_kernel(lib, X, topk, 1e-8, dev)
+    np.testing.assert_array_equal(ptr.cpu().numpy(), hp)
+    np.testing.assert_array_equal(idx.cpu().numpy(), hi)
+    np.testing.assert_allclose(val.cpu().numpy(), hv, rtol=1e-5, atol=2e-7)
+    np.testing.assert_allclose(D.cpu().numpy(), Sd.sum(axis=1), rtol=1e-4, atol=1e-5)
+    if topk == 128:
+        assert (hv < 0).any()                                   # the negative branch was exercised
+    # the product entry point takes the kernel path
+    p2, i2, v2, _ = layout.build_similarity_device(X, topk, 1e-8, dev, lib=lib)
+    assert torch.equal(p2, ptr) and torch.equal(i2, idx) and torch.equal(v2, val)
+
+
+@pytest.mark.parametrize("n,topk", [(500, 10), (2000, 50)])
+def test_kernel_tie_rule_on_binary_genres(n, topk):
+    """Multi-hot genres tie massively at the top-k boundary.  Documented rule: order by (similarity
+    descending, column index ascending), i.e. among equal similarities the lowest indices win.  Checked on the
+    top-k lists themselves against float64 similarities, plus symmetry of the final graph."""
+    import ctypes as C
+    torch, layout, lib, dev = _env()
+    from tests.synth import make_features
+    G, _ = make_features(n, 31)
+    Xn = G.astype(np.float64) / (np.sqrt((G.astype(np.float64) ** 2).sum(1, keepdims=True)) + 1e-8)
+    S64 = Xn @ Xn.T
+    np.fill_diagonal(S64, -np.inf)
+    ptr, idx, val, D = layout.build_similarity_kernel(lib, G, topk, 1e-8, dev)
+    ptr, idx, val = ptr.cpu().numpy(), idx.cpu().numpy(), val.cpu().numpy()
+    S = np.zeros((n, n), dtype=np.float32)
+    S[np.repeat(np.arange(n), np.diff(ptr)), idx] = val
+    assert np.array_equal(S, S.T) and not S.diagonal().any()
+    # recover the directed top-k lists: run the first kernel alone
+    Xd = torch.as_tensor(G, device=dev)
+    Xnd = Xd / (torch.sqrt((Xd * Xd).sum(1, keepdim=True)) + np.float32(1e-8))
+    n_pad = 16 * ((n + 15) // 16)
+    XT = torch.zeros(n_pad, 20, dtype=torch.float32, device=dev)
+    XT[:n, :19] = Xnd
+    XT = XT.view(n_pad, 5, 4).permute(1, 0, 2).contiguous()
+    tv = torch.empty(n, topk, dtype=torch.float32, device=dev)
+    ti = torch.empty(n, topk, dtype=torch.int32, device=dev)
+    tc = torch.empty(n, dtype=torch.int32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
+    assert lib.als_topk_similarity(n, n_pad, 5, p(XT), topk, p(tv), p(ti), p(tc), None) == 0
+    torch.cuda.synchronize()
+    tv, ti, tc = tv.cpu().numpy(), ti.cpu().numpy(), tc.cpu().numpy()
+    assert np.all(tc == topk)
+    ties_seen = 0
+    for i in range(n):
+        lv, li = tv[i], ti[i]
+        assert len(set(li.tolist())) == topk and i not in li
+        # ordered by (value descending, index ascending)
+        assert all(lv[t] > lv[t + 1] or (lv[t] == lv[t + 1] and li[t] < li[t + 1]) for t in range(topk - 1))
+        np.testing.assert_allclose(lv, S64[i, li], rtol=0, atol=2e-6)
+        tau = S64[i, li[-1]]
+        outside = np.setdiff1d(np.arange(n), np.append(li, i))
+        assert S64[i, outside].max() <= tau + 2e-6
+        tied = np.flatnonzero(np.abs(S64[i] - tau) <= 2e-6)             # boundary ties incl. chosen ones
+        chosen = np.intersect1d(tied, li)
+        if tied.size > chosen.size:
+            ties_seen += 1
+            np.testing.assert_array_equal(chosen, tied[: chosen.size])   # the lowest indices of the tie group
+    assert ties_seen > n // 2                                            # binary features do tie at the boundary
+
+
+def test_fallback_paths_and_argument_checks():
+    torch, layout, lib, dev = _env()
+    rng = np.random.default_rng(9)
+    X = rng.normal(size=(50, 5)).astype(np.float32)
+    for topk in (None, 50, 200):                  # keep-all cases go through the blocked torch formulation
+        Sd = layout.build_similarity_dense(X.copy(), topk, 1e-8)
+        hp, hi, hv = layout.dense_graph_to_csr(Sd)
+        ptr, idx, val, _ = layout.build_similarity_device(X, topk, 1e-8, dev, lib=lib)
+        np.testing.assert_array_equal(ptr.cpu().numpy(), hp)
+        np.testing.assert_array_equal(idx.cpu().numpy(), hi)
+    assert lib.als_topk_similarity(10, 10, 5, None, 5, None, None, None, None) < 0       # n_pad not a multiple of 16
+    assert lib.als_topk_similarity(16, 16, 3, None, 5, None, None, None, None) < 0

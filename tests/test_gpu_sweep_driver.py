@@ -99,3 +99,14 @@ def test_trial_protocol_reporting_and_pruning():
     with pytest.raises(sweep.SweepPruned):
         drv.cv_score(dict(PARAMS[0]), trial=t2)
     assert len(t2.reports) == 1
+
+
+def test_driver_with_captured_iterations_is_bitwise_the_eager_driver():
+    """hip_graph=True inside the driver: iterations after the first are replayed as captured HIP graphs while the
+    set-up products come from the shared cache - same launches on the same data, so identical scores."""
+    g, ratings, folds = _setup()
+    a = sweep.SweepDriver(ratings, g.features, folds).run([dict(p) for p in PARAMS])
+    b = sweep.SweepDriver(ratings, g.features, folds, als_kwargs={"hip_graph": True}).run([dict(p) for p in PARAMS])
+    for ta, tb in zip(a["trials"], b["trials"]):
+        assert ta["iters_per_fold"] == tb["iters_per_fold"]
+        assert ta["fold_rmse"] == tb["fold_rmse"]
