@@ -98,6 +98,32 @@ def gen_ratings(dev, m, n, nnz, seed):
     return csr, csc
 
 
+def graph_features(dev, n, seed):
+    """Item features the benchmark graph is built on: 19 genre-like binary columns at the shipped file's column
+    rates plus one small continuous column (N(0, 0.05^2)) - binary genres alone tie massively at the top-k
+    boundary; the extra column breaks those ties at random, which is what the reference's
+    argpartition does in effect.  float32 [n, 20] on the device."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    rates = torch.tensor(GENRE_RATES, device=dev)
+    G = (torch.rand(n, 19, device=dev, generator=g) < rates).to(torch.float32)
+    jitter = 0.05 * torch.randn(n, 1, device=dev, generator=g)
+    return torch.cat([G, jitter], dim=1)
+
+
+def gen_graph_product(dev, n, seed, topk=50):
+    """The benchmark's item graph built by the PRODUCT's own kernels (csrc/graph_build.hip through
+    layout.build_similarity_kernel): exact top-`topk` cosine neighbours of every item over all n items,
+    symmetrised by max.  Returns ((ptr, idx, val), seconds)."""
+    from collaborative_filtering_amd import _hip, layout
+    X = graph_features(dev, n, seed)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ptr, idx, val, _ = layout.build_similarity_kernel(_hip.load(), X, topk, 1e-8, dev)
+    torch.cuda.synchronize()
+    return (ptr, idx, val), time.perf_counter() - t0
+
+
 def gen_graph(dev, n, seed, topk=50, ncand=512):
     """Sparse item graph: each item keeps its `topk` genre-cosine neighbours among `ncand`
     random candidates; symmetrised by max; zero similarities are not edges."""
@@ -246,6 +272,9 @@ def main():
     ap.add_argument("--gram", default="bf16x3", choices=["bf16x3", "f32"],
                     help="how K1 forms the Gram: exact 3-way bf16 split on the bf16 matrix cores (fp32 "
                          "accumulate, fp32-level accuracy) or v_mfma_f32 on the raw floats")
+    ap.add_argument("--graph", default="product", choices=["product", "sampled"],
+                    help="item graph: exact top-50 cosine neighbours by the product's graph-build kernels (default), or "
+                         "round 1's stand-in (top-50 among 512 random candidates per item, torch ops)")
     ap.add_argument("--solve-dtype", default="float32", choices=["float32", "float64"],
                     help="float64: fp64 Gram / Cholesky / substitutions per row (accuracy mode; NOT the headline dtype)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -280,9 +309,15 @@ def main():
     # rank 0 generates, everybody receives the same bytes (robust against RNG differences)
     use_graph = (not args.no_graph) and args.size not in ("cfg2", "cfg3")
     features = gen_features(n, 3004) if args.size in ("cfg3", "cfg5-small", "cfg5") else None
+    graph_build_s = None
     if rank == 0:
         csr, csc = gen_ratings(dev, m, n, nnz, seed=1004)
-        S = gen_graph(dev, n, seed=2004) if use_graph else None
+        if not use_graph:
+            S = None
+        elif args.graph == "product":
+            S, graph_build_s = gen_graph_product(dev, n, seed=2004)
+        else:
+            S = gen_graph(dev, n, seed=2004)
     if dist_on:
         def bc(t, dtype, numel):
             if rank != 0:
@@ -413,6 +448,7 @@ def main():
                        "gram": args.gram, "solve_dtype": args.solve_dtype, "hip_graph": bool(args.hip_graph), "gs_mode": getattr(eng, "gs_mode", None), "gs_levels": (len(eng.sched.offsets) - 1)
                        if eng.use_graph else 0,
                        "parallelism": f"users/items sharded x{world}, all-gather of factor blocks",
+                       "graph": args.graph if use_graph else None, "graph_build_s": graph_build_s,
                        "setup_s": t_setup},
             "phase_ms_per_step": {kk: sum(v) / args.steps for kk, v in phase.items()},
             "train_rmse": [float(x) for x in hist[:, 0]],

@@ -630,6 +630,7 @@ class _Engine:
         self.hist = torch.zeros(max(model.n_iters, 1), 6, dtype=f64, device=device)
         self.hist_row = torch.zeros(6, dtype=f64, device=device)
         self._graphs = {}
+        self.graphs_captured = 0
         self.iters_run = 0
 
     # ------------------------------------------------------------- helpers
@@ -952,6 +953,7 @@ class _Engine:
             with torch.cuda.graph(g):
                 self._iteration_body(do_w, None)
             self._graphs[do_w] = g
+            self.graphs_captured += 1
         g.replay()
 
     def run(self, tol, min_iters, verbose):

@@ -131,8 +131,11 @@ void k_topk_sim(int64_t n, int64_t n_pad, const float* __restrict__ XT, int topk
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int64_t row = rowbase + 4 * q + e;
-            const unsigned long long key = ((unsigned long long)enc_f32(acc[e]) << 32) | (0xFFFFFFFFu - (unsigned)col);
-            const bool pass = col < n && row < n && col != row && key > thr[e];
+            // the zeroed diagonal takes part in the selection like any other entry (the reference selects over the
+            // whole row after np.fill_diagonal(S, 0): scripts/als.py:229-236); zeros are never edges
+            const float sim = (col == row) ? 0.f : acc[e];
+            const unsigned long long key = ((unsigned long long)enc_f32(sim) << 32) | (0xFFFFFFFFu - (unsigned)col);
+            const bool pass = col < n && row < n && key > thr[e];
             const unsigned long long m = __ballot(pass);
             const unsigned sub = (unsigned)(m >> (16 * q)) & 0xFFFFu;
             if (pass) keys[4 * q + e][TK_MAX + cnt[e] + __popc(sub & ((1u << c) - 1u))] = key;

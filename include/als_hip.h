@@ -314,10 +314,11 @@ int als_predict_dense(int k, int ld, int64_t m, int64_t n, const float* U,
  * Item-item similarity graph on the device (scripts/als.py:224-240 without the n x n matrix).
  * als_topk_similarity: XT is the row-normalised feature matrix Xn [n][d] (fp32) re-laid as [nsteps][n_pad][4]
  *   (feature dims in groups of 4, zero padded: nsteps in {1, 2, 4, 5, 8, 16}, i.e. d <= 64; n_pad a multiple of
- *   16, padding rows zero).  For every row i the topk (<= ALS_TOPK_MAX) largest similarities <xn_i, xn_j>, j != i,
- *   ordered by (similarity descending, j ascending) - among equal similarities the LOWEST column indices win (the
+ *   16, padding rows zero).  For every row i the topk (<= ALS_TOPK_MAX) largest entries of row i of Xn Xn^T with
+ *   its diagonal set to 0 (the diagonal entry competes like any other, as in the reference; zeros are never
+ *   edges), ordered by (similarity descending, j ascending) - among equal similarities the LOWEST column indices win (the
  *   reference's argpartition keeps an implementation-defined subset of such ties):
- *   top_val / top_idx [n][topk] (unused slots 0 / -1), top_cnt [n] = min(topk, n - 1).
+ *   top_val / top_idx [n][topk] (unused slots 0 / -1), top_cnt [n] = min(topk, n).
  * als_graph_classify: S = max(S, S^T) on those lists: own[i][t] = 1 when entry t of row i is an edge of the
  *   symmetric graph, mirror[i][t] = 1 when its transpose (j, i, s) must be added because j's list does not
  *   contain i (one-sided positive entries; one-sided negative ones and zeros are not edges).
