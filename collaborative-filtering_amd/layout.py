@@ -243,7 +243,10 @@ def build_similarity_kernel(lib, X, topk: int, eps: float, device, stream=None):
     surviving entries are sorted into CSR here.  fp32 throughout; d <= 64, topk <= 128, topk < n."""
     import ctypes as C
     import torch
-    Xd = torch.as_tensor(np.asarray(X, dtype=np.float32), device=device)
+    if torch.is_tensor(X):
+        Xd = X.to(device=device, dtype=torch.float32)
+    else:
+        Xd = torch.as_tensor(np.asarray(X, dtype=np.float32), device=device)
     n, d = Xd.shape
     Xn = Xd / (torch.sqrt((Xd * Xd).sum(1, keepdim=True)) + np.float32(eps))
     ns = next(s for s in (1, 2, 4, 5, 8, 16) if 4 * s >= d)
