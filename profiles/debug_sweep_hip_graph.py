@@ -1,7 +1,9 @@
-import json, os, sys, time
+import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
-from collaborative_filtering_amd import cv, sweep
+from collaborative_filtering_amd import cv
+from collaborative_filtering_amd.helpers import make_config, normalize_params
+from collaborative_filtering_amd import ALS
 from tests.synth import make_features, make_ratings
 m, n, nnz = 610, 4980, 100000
 rows, cols, vals = make_ratings(m, n, nnz, 5)
@@ -19,14 +21,24 @@ for t in range(12):
                        alpha=float(rng.uniform(0.1, 2.0)) if graph else 0.0,
                        graph_feature="genres" if graph else "__none__", S_topk=int(rng.choice([20, 50])),
                        lambda_w_genres=float(10 ** rng.uniform(-1, 1.5)), lambda_w_years=float(10 ** rng.uniform(-1, 1.5))))
-item_bin, _ = cv.popularity_bins(np.bincount(ratings.cols, minlength=n), 5)
-def harness(kw):
-    return [cv.eval_variant_cv("x", ratings, feats, folds, dict(p), item_bin, 5, cv.ES_TOL, cv.ES_MIN_ITERS, {}, als_kwargs=kw) for p in params]
-E = harness({}); H = harness({"hip_graph": True}); H2 = harness({"hip_graph": True})
-DE = sweep.SweepDriver(ratings, feats, folds).run([dict(p) for p in params])["trials"]
-DH = sweep.SweepDriver(ratings, feats, folds, als_kwargs={"hip_graph": True}).run([dict(p) for p in params])["trials"]
-for t, p in enumerate(params):
-    e, h, h2, de, dh = E[t][0], H[t][0], H2[t][0], DE[t]["fold_rmse"], DH[t]["fold_rmse"]
-    print(t, p["n_factors"], "graph" if p["alpha"] > 0 else "-", "iters E", E[t][3], "H", H[t][3], "DH", DH[t]["iters_per_fold"],
-          "E==DE", e == de, "E==H", e == h, "H==H2", h == h2, "E==DH", e == dh,
-          "max|E-H| %.2e" % max(abs(a - b) for a, b in zip(e, h)), "max|E-DH| %.2e" % max(abs(a - b) for a, b in zip(e, dh)))
+p = normalize_params(dict(params[4]), (m, n), list(feats))
+print(p)
+cfg = make_config(p)
+lw = {f: float(p[f"lambda_w_{f}"]) for f in feats}
+(tr, tc, tv), _, _ = cv.train_valid_split(ratings, folds, 0)
+
+def fit(hip, use_feats=True, tol=None):
+    md = ALS(cfg, lambda_w=lw if use_feats else None, hip_graph=hip)
+    md.fit_coo(tr, tc, tv, (m, n), features=feats if use_feats else {"genres": G}, tol=tol, min_iters=10, verbose=0)
+    return np.asarray(md.history["train_rmse"]), md
+
+for label, kw in (("features+graph", dict(use_feats=True)), ("graph only (genres kept for the graph, lambda_w=0 quirk -> still fitted)", dict(use_feats=False))):
+    for df in ("1", "0"):
+        os.environ["ALS_GS_DATAFLOW"] = df
+        e, _ = fit(False, **kw)
+        for rep in range(3):
+            h, md = fit(True, **kw)
+            d = np.abs(e - h)
+            first = int(np.argmax(d > 0)) if (d > 0).any() else -1
+            print(label, "dataflow", df, "rep", rep, "max|eager-replay| %.3e" % d.max(), "first differing iteration", first,
+                  "captured", md._eng.graphs_captured, flush=True)
