@@ -988,7 +988,8 @@ class _Engine:
         for it in range(n_iters):
             self.iteration(it, n_iters)
             if tol is not None and it + 1 >= min_iters:                           # :520-523
-                self._check_status()
+                if os.environ.get("ALS_DBG_NOCHECK") != "1":
+                    self._check_status()
                 h = self.hist[: it + 1, 0].cpu().numpy()
                 if len(h) + base_len >= 3:
                     prev = (list(rm) + list(h))[-3]
@@ -997,7 +998,8 @@ class _Engine:
                             logger.info("Early stopping at iter %d; dRMSE <= %.3g", it + 1, tol)
                         break
         self._check_status()
-        self._graphs.clear()            # captured iteration graphs are not needed past the fit
+        if os.environ.get("ALS_DBG_NOCLEAR") != "1":
+            self._graphs.clear()            # captured iteration graphs are not needed past the fit
 
     # --------------------------------------------------------------- export
     def export(self, model: ALS):

@@ -32,13 +32,14 @@ def fit(hip, use_feats=True, tol=None):
     md.fit_coo(tr, tc, tv, (m, n), features=feats if use_feats else {"genres": G}, tol=tol, min_iters=10, verbose=0)
     return np.asarray(md.history["train_rmse"]), md
 
-for label, kw in (("features+graph", dict(use_feats=True)), ("graph only (genres kept for the graph, lambda_w=0 quirk -> still fitted)", dict(use_feats=False))):
-    for df in ("1", "0"):
-        os.environ["ALS_GS_DATAFLOW"] = df
-        e, _ = fit(False, **kw)
+for noclear in ("0", "1"):
+    for nocheck in ("0", "1"):
+        os.environ["ALS_DBG_NOCLEAR"], os.environ["ALS_DBG_NOCHECK"] = noclear, nocheck
+        e, me = fit(False, tol=1e-4)
         for rep in range(3):
-            h, md = fit(True, **kw)
-            d = np.abs(e - h)
+            h, md = fit(True, tol=1e-4)
+            nn = min(len(e), len(h))
+            d = np.abs(e[:nn] - h[:nn])
             first = int(np.argmax(d > 0)) if (d > 0).any() else -1
-            print(label, "dataflow", df, "rep", rep, "max|eager-replay| %.3e" % d.max(), "first differing iteration", first,
-                  "captured", md._eng.graphs_captured, flush=True)
+            print("noclear", noclear, "nocheck", nocheck, "rep", rep, "iters", len(e), len(h), "max|eager-replay| %.3e" % d.max(),
+                  "first differing iteration", first, "|dU| %.3e" % np.abs(me.U - md.U).max() if len(e) == len(h) else "", flush=True)
