@@ -32,12 +32,17 @@ def fit(hip, use_feats=True, tol=None):
     md.fit_coo(tr, tc, tv, (m, n), features=feats if use_feats else {"genres": G}, tol=tol, min_iters=10, verbose=0)
     return np.asarray(md.history["train_rmse"]), md
 
-import logging
-logging.basicConfig(level=logging.WARNING)
+import gc
 os.environ["ALS_DBG_NOCLEAR"], os.environ["ALS_DBG_NOCHECK"] = "0", "0"
 e, me = fit(False, tol=1e-4)
-for rep in range(4):
-    h, md = fit(True, tol=1e-4)
-    print("rep", rep, "iters", len(e), len(h), "dataflow still on:", md._dataflow_sweep, "graphs captured", md._eng.graphs_captured)
-    for it in range(17, min(len(e), len(h))):
-        print("   it", it, "eager %.10f replay %.10f diff %.3e" % (e[it], h[it], abs(e[it] - h[it])))
+for mode in ("gc enabled", "gc disabled", "gc enabled again"):
+    if mode == "gc disabled":
+        gc.collect(); gc.disable()
+    else:
+        gc.enable()
+    for rep in range(2):
+        h, md = fit(True, tol=1e-4)
+        nn = min(len(e), len(h))
+        d = np.abs(e[:nn] - h[:nn])
+        print(mode, "rep", rep, "iters", len(e), len(h), "max diff %.3e" % d.max(), "first", int(np.argmax(d > 0)) if (d > 0).any() else -1,
+              "gc counts", gc.get_count(), flush=True)
