@@ -988,8 +988,19 @@ class _Engine:
         for it in range(n_iters):
             self.iteration(it, n_iters)
             if tol is not None and it + 1 >= min_iters:                           # :520-523
-                if os.environ.get("ALS_DBG_NOCHECK") != "1":
+                dbg = os.environ.get("ALS_DBG_CHECK", "all")
+                if dbg == "all":
                     self._check_status()
+                elif dbg == "gs":
+                    int(self.gs_err.item())
+                elif dbg == "w":
+                    int(self.w_bad.item())
+                elif dbg == "st":
+                    int(self.status.item())
+                elif dbg == "dummy3":
+                    int(self.ss[0].item()); int(self.ss[1].item()); int(self.ss[2].item())
+                elif dbg == "sync3":
+                    torch.cuda.synchronize(); torch.cuda.synchronize(); torch.cuda.synchronize()
                 h = self.hist[: it + 1, 0].cpu().numpy()
                 if len(h) + base_len >= 3:
                     prev = (list(rm) + list(h))[-3]

@@ -32,17 +32,10 @@ def fit(hip, use_feats=True, tol=None):
     md.fit_coo(tr, tc, tv, (m, n), features=feats if use_feats else {"genres": G}, tol=tol, min_iters=10, verbose=0)
     return np.asarray(md.history["train_rmse"]), md
 
-import gc
-os.environ["ALS_DBG_NOCLEAR"], os.environ["ALS_DBG_NOCHECK"] = "0", "0"
 e, me = fit(False, tol=1e-4)
-for mode in ("gc enabled", "gc disabled", "gc enabled again"):
-    if mode == "gc disabled":
-        gc.collect(); gc.disable()
-    else:
-        gc.enable()
-    for rep in range(2):
-        h, md = fit(True, tol=1e-4)
-        nn = min(len(e), len(h))
-        d = np.abs(e[:nn] - h[:nn])
-        print(mode, "rep", rep, "iters", len(e), len(h), "max diff %.3e" % d.max(), "first", int(np.argmax(d > 0)) if (d > 0).any() else -1,
-              "gc counts", gc.get_count(), flush=True)
+for mode in ("all", "gs", "w", "st", "dummy3", "sync3", "none"):
+    os.environ["ALS_DBG_CHECK"] = mode
+    h, md = fit(True, tol=1e-4)
+    nn = min(len(e), len(h))
+    d = np.abs(e[:nn] - h[:nn])
+    print(mode, "iters", len(e), len(h), "max diff %.3e" % d.max(), "first", int(np.argmax(d > 0)) if (d > 0).any() else -1, flush=True)
