@@ -653,6 +653,7 @@ class _Engine:
         self.hist_row = torch.zeros(6, dtype=f64, device=device)
         self._graphs = {}
         self.graphs_captured = 0
+        self.replay_ok = True           # run() clears it for fits with early stopping (see there)
         self.iters_run = 0
 
     # ------------------------------------------------------------- helpers
@@ -945,7 +946,7 @@ class _Engine:
             with torch.cuda.device(self.dev):          # callers that drive iterations themselves (bench.py)
                 return self.iteration(it, n_iters)
         do_w = bool(self.feat_names) and ((it % md.update_w_every == 0) or (it == n_iters - 1))   # :468
-        if self.model._hip_graph and not self.multi and self.timers is None and it > 0:
+        if self.model._hip_graph and self.replay_ok and not self.multi and self.timers is None and it > 0:
             self._replay(do_w)
             self.hist[it].copy_(self.hist_row)
         else:
@@ -983,24 +984,19 @@ class _Engine:
         n_iters = int(md.n_iters)
         rm = md.history["train_rmse"]
         base_len = len(rm)
+        # Captured-graph replay (hip_graph=True) is used for fits WITHOUT early stopping only.  With `tol` the host
+        # reads the status words and the RMSE history back after every iteration; on this ROCm runtime (7.2) those
+        # device-to-host copies between launches of an instantiated graph corrupt later replays - the iteration
+        # after a few dozen interleaved copies computes garbage (reproduced by profiles/debug_sweep_hip_graph.py:
+        # bitwise equal to the eager fit with tol=None, garbage from iteration 21 / 24 with 3 / 1 `.item()` reads per
+        # iteration in between).  Such fits run eagerly.
+        self.replay_ok = tol is None
         if self.feat_names:
             self.be.compose_z(self.V, self.Xcat, self.Wcat, self.Z)              # :411
         for it in range(n_iters):
             self.iteration(it, n_iters)
             if tol is not None and it + 1 >= min_iters:                           # :520-523
-                dbg = os.environ.get("ALS_DBG_CHECK", "all")
-                if dbg == "all":
-                    self._check_status()
-                elif dbg == "gs":
-                    int(self.gs_err.item())
-                elif dbg == "w":
-                    int(self.w_bad.item())
-                elif dbg == "st":
-                    int(self.status.item())
-                elif dbg == "dummy3":
-                    int(self.ss[0].item()); int(self.ss[1].item()); int(self.ss[2].item())
-                elif dbg == "sync3":
-                    torch.cuda.synchronize(); torch.cuda.synchronize(); torch.cuda.synchronize()
+                self._check_status()
                 h = self.hist[: it + 1, 0].cpu().numpy()
                 if len(h) + base_len >= 3:
                     prev = (list(rm) + list(h))[-3]
@@ -1009,8 +1005,7 @@ class _Engine:
                             logger.info("Early stopping at iter %d; dRMSE <= %.3g", it + 1, tol)
                         break
         self._check_status()
-        if os.environ.get("ALS_DBG_NOCLEAR") != "1":
-            self._graphs.clear()            # captured iteration graphs are not needed past the fit
+        self._graphs.clear()            # captured iteration graphs are not needed past the fit
 
     # --------------------------------------------------------------- export
     def export(self, model: ALS):
