@@ -18,7 +18,7 @@ MAX_K = 160                 # ALS_MAX_K
 
 EXPORTS = ("als_version", "als_padded_k", "als_perm_index", "als_partial_slot_bytes", "als_partial_slot_bytes_f64",
            "als_row_solve", "als_gs_sweep", "als_gs_sweep_levels", "als_gs_sweep_dataflow", "als_residual_stats", "als_w_normal_equations", "als_spd_solve_workspace_bytes", "als_spd_solve_f64", "als_item_stats", "als_sum_pairs", "als_sumsq_partials",
-           "als_sumsq", "als_compose_z", "als_predict_at", "als_predict_dense",
+           "als_sumsq", "als_history_row", "als_compose_z", "als_predict_at", "als_predict_dense",
            "als_topk_similarity", "als_graph_classify",
            "als_host_coo_to_sides", "als_host_row_tasks", "als_host_level_schedule")
 
@@ -107,6 +107,7 @@ def load():
     lib.als_spd_solve_f64.argtypes = [_i64, _vp, _i64, _vp, C.c_double, _vp, _vp, _vp, _vp]
     lib.als_sumsq.argtypes = [_vp, _i64, _vp, _vp, _vp]
     lib.als_sum_pairs.argtypes = [_vp, _i64, _vp, _vp, _vp]
+    lib.als_history_row.argtypes = [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]
     lib.als_compose_z.argtypes = [_i64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
     lib.als_predict_at.argtypes = [C.c_int, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.als_predict_dense.argtypes = [C.c_int, C.c_int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]

@@ -927,14 +927,18 @@ class _Engine:
                 self.be.residual_stats(k=self.k, ld=self.ld, side=self.csr, U=self.U, Z=self.Z, b_u=self.b_u,
                                        b_i=self.b_i, mu=self.mu, tasks=self.utasks, out=self.stats)
         self._allreduce(self.stats)
-        for j, t in enumerate((self.U, self.V, self.b_u, self.b_i)):
-            self.be.sumsq(t, self.ss[j:j + 1])
-        mean_d = self.stats[0] / self.nnz
-        self.mu += mean_d
         h = self.hist_row                 # fixed address: the iteration can be replayed as a captured graph
-        h[0] = torch.sqrt(torch.clamp(self.stats[1] / self.nnz - mean_d * mean_d, min=0.0))
-        h[1:5] = torch.sqrt(self.ss)
-        h[5] = self.mu[0]
+        if hasattr(self.be, "history_row"):
+            self.be.history_row(U=self.U, V=self.V, b_u=self.b_u, b_i=self.b_i, stats=self.stats, nnz=self.nnz,
+                                mu=self.mu, row=h)
+        else:
+            for j, t in enumerate((self.U, self.V, self.b_u, self.b_i)):
+                self.be.sumsq(t, self.ss[j:j + 1])
+            mean_d = self.stats[0] / self.nnz
+            self.mu += mean_d
+            h[0] = torch.sqrt(torch.clamp(self.stats[1] / self.nnz - mean_d * mean_d, min=0.0))
+            h[1:5] = torch.sqrt(self.ss)
+            h[5] = self.mu[0]
         if it is not None:
             self.hist[it].copy_(h)
 

@@ -196,9 +196,19 @@ class HipBackend:
     def sum_pairs(self, x: torch.Tensor, out: torch.Tensor):
         """out[0:2] = column sums of x viewed as [n, 2] (fp64, deterministic)."""
         x = getattr(x, "t", x)              # a rank-local by-product array (als._RowShift): reduce what exists
-        part = torch.empty(2 * self._sumsq_partials.numel(), dtype=torch.float64, device=self.device)
+        if getattr(self, "_pair_partials", None) is None:
+            self._pair_partials = torch.empty(2 * self._sumsq_partials.numel(), dtype=torch.float64, device=self.device)
+        part = self._pair_partials
         self._check(self.lib.als_sum_pairs(_p(x), x.numel() // 2, _p(part), _p(out), self._stream()),
                     "als_sum_pairs")
+
+    def history_row(self, *, U, V, b_u, b_i, stats, nnz, mu, row):
+        """mu update + the five history values of an iteration in two launches (als_history_row)."""
+        if getattr(self, "_hist_partials", None) is None:
+            self._hist_partials = torch.empty(4 * self._sumsq_partials.numel(), dtype=torch.float64, device=self.device)
+        self._check(self.lib.als_history_row(_p(U), U.numel(), _p(V), V.numel(), _p(b_u), b_u.numel(), _p(b_i), b_i.numel(),
+                                             _p(stats), int(nnz), _p(mu), _p(self._hist_partials), _p(row), self._stream()),
+                    "als_history_row")
 
     def sumsq(self, x: torch.Tensor, out: torch.Tensor):
         self._check(self.lib.als_sumsq(_p(x), x.numel(), _p(self._sumsq_partials), _p(out),

@@ -144,6 +144,65 @@ void k_sum_pairs_partial(const float* __restrict__ x, int64_t npairs, double* __
     if (threadIdx.x == 0) { partials[2 * blockIdx.x] = red[0]; partials[2 * blockIdx.x + 1] = red[256]; }
 }
 
+// The history row of an iteration in two launches (scripts/als.py:505-517): sums of squares of U, V, b_u, b_i
+// (blockIdx.y picks the array, same per-array partition as als_sumsq) ...
+struct Norm4 { const float* x[4]; int64_t n[4]; int nblk[4]; };
+
+__global__ __launch_bounds__(256)
+void k_sumsq4_partial(const Norm4 a, double* __restrict__ partials) {
+    __shared__ double red[256];
+    const int j = blockIdx.y;
+    if ((int)blockIdx.x >= a.nblk[j]) return;
+    const float* x = a.x[j];
+    const int64_t n = a.n[j], n4 = n >> 2;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)a.nblk[j] * 256) {
+        const f32x4 v = x4[i];
+        acc += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const double v = x[(n4 << 2) + threadIdx.x];
+        acc += v * v;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[(int64_t)j * SUMSQ_BLOCKS + blockIdx.x] = red[0];
+}
+
+// ... then the final sums and the scalar arithmetic of the row: mu += mean(d), RMSE = sqrt(mean(d^2) - mean(d)^2),
+// the four norms.  fp64, no contraction (the same operations the host would do one by one).
+__global__ __launch_bounds__(256)
+void k_history_final(const Norm4 a, const double* __restrict__ partials, const double* __restrict__ stats, double nnz,
+                     double* __restrict__ mu, double* __restrict__ row) {
+#pragma clang fp contract(off)
+    __shared__ double red[4][256];
+    for (int j = 0; j < 4; ++j) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < a.nblk[j]; i += 256) acc += partials[(int64_t)j * SUMSQ_BLOCKS + i];
+        red[j][threadIdx.x] = acc;
+    }
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int j = 0; j < 4; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mean_d = stats[0] / nnz;
+        const double m = *mu + mean_d;
+        const double var = stats[1] / nnz - mean_d * mean_d;
+        *mu = m;
+        row[0] = sqrt(var > 0.0 ? var : 0.0);
+        for (int j = 0; j < 4; ++j) row[1 + j] = sqrt(red[j][0]);
+        row[5] = m;
+    }
+}
+
 template <int KB>
 int launch_stats(int ld, const int64_t* indptr, const int32_t* indices, const float* vals,
                  const float* U, const float* Z, const float* b_u, const float* b_i,
@@ -201,5 +260,28 @@ extern "C" int als_sumsq(const float* x, int64_t n, double* partials, double* ou
     if (nblk > SUMSQ_BLOCKS) nblk = SUMSQ_BLOCKS;
     hipLaunchKernelGGL(k_sumsq_partial, dim3((unsigned)nblk), dim3(256), 0, st, x, n, partials);
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, st, partials, nblk, 1, out);
+    return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
+}
+
+extern "C" int als_history_row(const float* U, int64_t nU, const float* V, int64_t nV, const float* b_u, int64_t nbu,
+                               const float* b_i, int64_t nbi, const double* stats, int64_t nnz, double* mu,
+                               double* partials, double* row, void* stream) {
+    if (!U || !V || !b_u || !b_i || !stats || !mu || !partials || !row || nnz < 1 || nU < 0 || nV < 0 || nbu < 0 || nbi < 0)
+        return ALS_E_BADARG;
+    Norm4 a;
+    const float* xs[4] = {U, V, b_u, b_i};
+    const int64_t ns[4] = {nU, nV, nbu, nbi};
+    int maxblk = 1;
+    for (int j = 0; j < 4; ++j) {
+        if (((uintptr_t)xs[j] & 15) != 0) return ALS_E_BADARG;
+        int64_t nblk = (ns[j] / 4 + 255) / 256;
+        if (nblk < 1) nblk = 1;
+        if (nblk > SUMSQ_BLOCKS) nblk = SUMSQ_BLOCKS;
+        a.x[j] = xs[j]; a.n[j] = ns[j]; a.nblk[j] = (int)nblk;
+        if (nblk > maxblk) maxblk = (int)nblk;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_sumsq4_partial, dim3((unsigned)maxblk, 4), dim3(256), 0, st, a, partials);
+    hipLaunchKernelGGL(k_history_final, dim3(1), dim3(256), 0, st, a, partials, stats, (double)nnz, mu, row);
     return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
 }

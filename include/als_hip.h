@@ -294,6 +294,14 @@ int als_sum_pairs(const float* x, int64_t npairs, double* partials, double* out,
 int als_sumsq_partials(void);
 int als_sumsq(const float* x, int64_t n, double* partials, double* out, void* stream);
 
+/* The history row of an iteration in two launches (scripts/als.py:505-517): stats = (sum d, sum d^2) of the residuals
+ * before the mu update (als_sum_pairs / als_residual_stats), nnz ratings.  mu (device double) += sum d / nnz;
+ * row[6] = {train RMSE with the new mu, |U|_F, |V|_F, |b_u|, |b_i|, mu}.  The arrays must be 16-byte aligned.
+ * partials: scratch of 4 * als_sumsq_partials() doubles. */
+int als_history_row(const float* U, int64_t nU, const float* V, int64_t nV, const float* b_u, int64_t nbu,
+                    const float* b_i, int64_t nbi, const double* stats, int64_t nnz, double* mu,
+                    double* partials, double* row, void* stream);
+
 /* Z = V + X W  (scripts/als.py:262-281); X [n][D] fp32 (all features
  * concatenated column-wise), W [D][ld] fp32.  D == 0 copies V. */
 int als_compose_z(int64_t n, int ld, int D, const float* V, const float* X,

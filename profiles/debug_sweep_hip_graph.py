@@ -29,7 +29,7 @@ lw = {f: float(p[f"lambda_w_{f}"]) for f in feats}
 (tr, tc, tv), _, _ = cv.train_valid_split(ratings, folds, 0)
 
 
-def fit(hip, reads):
+def fit(hip, mode):
     md = ALS(cfg, lambda_w=lw, hip_graph=hip)
     csr, csc = __import__("collaborative_filtering_amd").layout.coo_to_sides(tr, tc, tv, (m, n))
     md._fit_sides(csr, csc, feats, None, 0, 0, None, run=False)
@@ -37,15 +37,20 @@ def fit(hip, reads):
     eng.be.compose_z(eng.V, eng.Xcat, eng.Wcat, eng.Z)
     for it in range(30):
         eng.iteration(it, 30)
-        for _ in range(reads):
-            int(eng.status.item())
+        if it >= 9:
+            if "status" in mode:
+                eng._check_status()                      # three .item() reads
+            if "slice" in mode:
+                eng.hist[: it + 1, 0].cpu().numpy()      # strided view: a device temporary + a D2H copy
+            if "row" in mode:
+                eng.hist_row.cpu().numpy()               # contiguous 6 doubles: a D2H copy only
     torch.cuda.synchronize()
     return eng.hist[:30, 0].cpu().numpy()
 
 
-e = fit(False, 0)
-for reads in (0, 1, 3):
-    h = fit(True, reads)
+e = fit(False, "")
+for mode in ("", "status", "slice", "row", "status+slice", "status+row"):
+    h = fit(True, mode)
     d = np.abs(e - h)
-    print(f"replay with {reads} read-back(s) per iteration: max |eager - replay| = {d.max():.3e}, first differing iteration "
-          f"{int(np.argmax(d > 0)) if (d > 0).any() else -1}", flush=True)
+    print(f"replay, host reads after every iteration >= 9: [{mode or 'none'}]: max |eager - replay| = {d.max():.3e}, "
+          f"first differing iteration {int(np.argmax(d > 0)) if (d > 0).any() else -1}", flush=True)
