@@ -272,9 +272,12 @@ def main():
     ap.add_argument("--gram", default="bf16x3", choices=["bf16x3", "f32"],
                     help="how K1 forms the Gram: exact 3-way bf16 split on the bf16 matrix cores (fp32 "
                          "accumulate, fp32-level accuracy) or v_mfma_f32 on the raw floats")
-    ap.add_argument("--graph", default="product", choices=["product", "sampled"],
-                    help="item graph: exact top-50 cosine neighbours by the product's graph-build kernels (default), or "
-                         "round 1's stand-in (top-50 among 512 random candidates per item, torch ops)")
+    ap.add_argument("--graph", default="sampled", choices=["sampled", "product"],
+                    help="item graph: SURVEY 8(d)'s workload definition (default; every item's top-50 genre-cosine "
+                         "neighbours among 512 random candidates, symmetrised by max - the graph every number since "
+                         "round 1 was measured on), or the exact top-50 over ALL items built by the product's own "
+                         "kernels (csrc/graph_build.hip; 34 ms at n = 100K, 2.7 s at n = 1M - hub items with thousands "
+                         "of neighbours then lengthen the sweep: 2.7 instead of 1.4 ms at cfg 4)")
     ap.add_argument("--solve-dtype", default="float32", choices=["float32", "float64"],
                     help="float64: fp64 Gram / Cholesky / substitutions per row (accuracy mode; NOT the headline dtype)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Reproducer kept for the record: replaying a captured iteration graph with device-to-host
-read-backs between the launches goes wrong on ROCm 7.2.  The engine therefore replays graphs only for fits without
-early stopping; this script drives the engine by hand to show the effect: one reference-scale fit (610 x 4980,
-k = 16, features + Laplacian), 30 iterations, (a) eager, (b) replay with no host reads in between, (c) replay with
-`reads` scalar read-backs after every iteration."""
+"""Reproducer kept for the record: replaying the captured iteration graphs while the host reads
+the engine's status words / history back between the launches - what early stopping needs - goes wrong on this
+image (ROCm 7.2, torch 2.10): from some iteration on the replays compute garbage.  The engine therefore replays
+graphs only for fits without early stopping.  One reference-scale fit (610 x 4980, k = 16, features + Laplacian),
+30 iterations, eager against replay with different host reads after every iteration >= 9."""
 import os
 import sys
 
@@ -50,7 +50,11 @@ def fit(hip, mode):
 
 e = fit(False, "")
 for mode in ("", "status", "slice", "row", "status+slice", "status+row"):
-    h = fit(True, mode)
+    try:
+        h = fit(True, mode)
+    except Exception as ex:          # noqa: BLE001 - the corrupted state usually ends in "not positive definite"
+        print(f"replay, host reads after every iteration >= 9: [{mode}]: the fit went wrong: {type(ex).__name__}: {ex}", flush=True)
+        continue
     d = np.abs(e - h)
     print(f"replay, host reads after every iteration >= 9: [{mode or 'none'}]: max |eager - replay| = {d.max():.3e}, "
           f"first differing iteration {int(np.argmax(d > 0)) if (d > 0).any() else -1}", flush=True)

@@ -100,3 +100,39 @@ def test_fallback_paths_and_argument_checks():
         np.testing.assert_array_equal(idx.cpu().numpy(), hi)
     assert lib.als_topk_similarity(10, 10, 5, None, 5, None, None, None, None) < 0       # n_pad not a multiple of 16
     assert lib.als_topk_similarity(16, 16, 3, None, 5, None, None, None, None) < 0
+
+
+def test_product_graph_at_the_cfg4_item_count():
+    """n = 100 000 items (BASELINE configs[3]) through the product entry point, on bench.py's graph features
+    (19 genre-like binary columns + a small continuous column): the exact top-50 over ALL items.  Sampled rows
+    are checked against float64 similarities computed on the host for those rows."""
+    torch, layout, lib, dev = _env()
+    import bench
+    n, topk = 100_000, 50
+    X = bench.graph_features(dev, n, seed=2004)
+    ptr, idx, val, D = layout.build_similarity_device(X, topk, 1e-8, dev, lib=lib)
+    ptr_h, idx_h, val_h = ptr.cpu().numpy(), idx.cpu().numpy(), val.cpu().numpy()
+    deg = np.diff(ptr_h)
+    assert deg.min() >= 1 and deg.mean() > topk and idx_h.size == ptr_h[-1]
+    Xh = X.cpu().numpy().astype(np.float64)
+    Xn = Xh / (np.sqrt((Xh * Xh).sum(1, keepdims=True)) + 1e-8)
+    rng = np.random.default_rng(3)
+    for i in rng.integers(0, n, size=20):
+        s = Xn @ Xn[i]
+        s[i] = 0.0
+        want = np.argsort(-s, kind="stable")[:topk]                 # distinct similarities: the set is unique
+        want = want[s[want] != 0.0]
+        row = idx_h[ptr_h[i]:ptr_h[i + 1]]
+        assert np.isin(want, row).all()                             # own top-k (the rest are mirrored entries)
+        pos = np.searchsorted(row, want)
+        np.testing.assert_allclose(val_h[ptr_h[i]:ptr_h[i + 1]][pos], s[want], rtol=0, atol=2e-6)
+        # every mirrored entry j of row i has i among j's own top-k
+        for j in np.setdiff1d(row, want)[:5]:
+            sj = Xn @ Xn[j]
+            sj[j] = 0.0
+            assert i in np.argsort(-sj, kind="stable")[:topk]
+    # symmetric: the transposed pattern is the pattern
+    rows = np.repeat(np.arange(n), deg)
+    key = rows * n + idx_h
+    tkey = np.sort(idx_h.astype(np.int64) * n + rows)
+    assert np.array_equal(key, tkey)
