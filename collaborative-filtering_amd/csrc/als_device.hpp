@@ -117,7 +117,10 @@ struct KCfg {
     // a 2-way conflict on ds_write_b32 / ds_read_b32 hides behind the instruction's own issue cycles.)
     // waves per workgroup / minimum waves per SIMD asked of the register allocator
     static constexpr int WPW = (KB <= 4) ? 4 : (KB <= 6 ? 2 : 1);
-    static constexpr int MINW = (KB <= 4) ? 3 : (KB <= 6 ? 2 : 1);
+#ifndef ALS_MINW4
+#define ALS_MINW4 0
+#endif
+    static constexpr int MINW = (KB <= 4) ? (ALS_MINW4 ? 4 : 3) : (KB <= 6 ? 2 : 1);
     static constexpr int SLOT_ITEMS = NACC * 4 + 2 * KB + 2;  // per-lane floats of a partial
     // gather steps (4 ratings each) staged in registers at a time
     static constexpr int GS = (KB <= 8) ? 8 : 4;

@@ -173,6 +173,65 @@ __device__ __forceinline__ void process_chunk_bf16x3(RowAcc<KB>& A, int off_l, f
     }
 }
 
+// The same Gram in groups of 16 ratings on v_mfma_f32_16x16x16_bf16 (4 k-elements per lane): lane (c,q) takes
+// ratings 4q .. 4q+3 of a 16-rating group.  Half the operand and staging registers of the 32-rating form
+// (H / M / L: 24 instead of 48, gathered rows: 4 x KB instead of 8 x KB), twice the MFMA instructions.
+#ifndef ALS_GRAM_G16
+#define ALS_GRAM_G16 0
+#endif
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+template <int KB, bool FULL>
+__device__ __forceinline__ void process_chunk_bf16x3_g16(RowAcc<KB>& A, int off_l, float r_l, int nvalid,
+                                                         const float* __restrict__ Fc, int q) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (!FULL && 16 * g >= nvalid) break;
+        int off_t[4];
+        float r_t[4];
+        float f[4][KB];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            off_t[j] = bperm_i(off_l, 16 * g + 4 * q + j);
+            r_t[j] = bperm_f(r_l, 16 * g + 4 * q + j);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load_frow<KB>(Fc + (uint32_t)off_t[j], f[j]);
+        i32x2 H[KB], M[KB], L[KB];
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const float x0 = f[j][b], x1 = f[j + 1][b];
+                A.rhs[b] = fmaf(x0, r_t[j], A.rhs[b]);
+                A.rhs[b] = fmaf(x1, r_t[j + 1], A.rhs[b]);
+                A.cs[b] += x0 + x1;
+                int hw, mw, lw;
+                split3(x0, x1, hw, mw, lw);
+                H[b][j >> 1] = hw; M[b][j >> 1] = mw; L[b][j >> 1] = lw;
+            }
+        }
+#pragma unroll
+        for (int bi = 0; bi < KB; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) {
+                f32x4 acc = A.acc[blk_idx(bi, bj)];
+                const bf16x4 hi = __builtin_bit_cast(bf16x4, H[bi]), hj = __builtin_bit_cast(bf16x4, H[bj]);
+                const bf16x4 mi = __builtin_bit_cast(bf16x4, M[bi]), mj = __builtin_bit_cast(bf16x4, M[bj]);
+                const bf16x4 li = __builtin_bit_cast(bf16x4, L[bi]), lj = __builtin_bit_cast(bf16x4, L[bj]);
+                // smallest terms first
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(li, hj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi, lj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(mi, mj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(mi, hj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi, mj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi, hj, acc, 0, 0, 0);
+                A.acc[blk_idx(bi, bj)] = acc;
+            }
+    }
+}
+
 // Long rows in bf16x3 mode: the bf16 MFMA's internal accumulation error grows linearly with the
 // number of accumulated groups (measured 1e-5 relative at 4000 ratings vs 3e-6 for f32 MFMA), so
 // every FLUSH_GROUPS*32 ratings the accumulators are added (fp32, round-to-nearest) into totals
@@ -237,8 +296,13 @@ __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __
             if (nvalid == 64) process_chunk<KB, true>(A, off0, r0, 64, Fc, q);
             else              process_chunk<KB, false>(A, off0, r0, nvalid, Fc, q);
         } else {
+#if ALS_GRAM_G16
+            if (nvalid == 64) process_chunk_bf16x3_g16<KB, true>(A, off0, r0, 64, Fc, q);
+            else              process_chunk_bf16x3_g16<KB, false>(A, off0, r0, nvalid, Fc, q);
+#else
             if (nvalid == 64) process_chunk_bf16x3<KB, true>(A, off0, r0, 64, Fc, q);
             else              process_chunk_bf16x3<KB, false>(A, off0, r0, nvalid, Fc, q);
+#endif
             if (((base >> 6) + 1) % (FLUSH_GROUPS / 2) == 0 && base + 64 < len) {
                 flush_acc<KB>(A, Ls, lane, nflush == 0);
                 ++nflush;
