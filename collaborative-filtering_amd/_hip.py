@@ -97,7 +97,7 @@ def load():
     lib.als_row_solve.argtypes = [C.POINTER(RowSolveParams), _vp]
     lib.als_gs_sweep.argtypes = [C.POINTER(GsSweepParams), _vp]
     lib.als_gs_sweep_levels.argtypes = [C.POINTER(GsSweepParams), _vp, _i64, _vp]
-    lib.als_gs_sweep_dataflow.argtypes = [C.POINTER(GsSweepParams), _vp, _vp, _i64, _vp, _vp]
+    lib.als_gs_sweep_dataflow.argtypes = [C.POINTER(GsSweepParams), _vp, _vp, _i64, _vp, _vp, _vp]
     lib.als_residual_stats.argtypes = [C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _i64, _vp, _vp, _vp]
     lib.als_w_normal_equations.argtypes = [C.POINTER(WParams), _vp]

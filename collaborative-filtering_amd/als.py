@@ -611,6 +611,10 @@ class _Engine:
                 self.S_idx_wait = wait_dev
                 self.gs_publish = torch.empty(n_pad, self.ld, dtype=f32, device=device)       # same shape as V
                 self.gs_err = torch.zeros(1, dtype=torch.int32, device=device)
+                # neighbour sums that do not depend on the sweep, formed for all items at once before it
+                # (ALS_GS_NONDEP=0: inside the sweep, as in round 1)
+                self.gs_nondep = (torch.empty(n_pad, self.ld, dtype=f32, device=device)
+                                  if os.environ.get("ALS_GS_NONDEP", "1") != "0" else None)
         # By-products of the V-step exist for this rank's items only ([ib, ie): n / world rows instead of n - the
         # item Grams and Cholesky factors are n * ld^2 floats each, 65 GB at BASELINE configs[4]); the kernels index
         # them with absolute item ids through a shifted base pointer (_RowShift).  The numpy stand-in of the CPU
@@ -823,7 +827,7 @@ class _Engine:
             kw.update(sumr2=self.sumr2, lambda_eff=self.lam_eff, stat_out=self.stat_rows)
         if self.gs_dataflow:
             self.be.gs_dataflow(items=self.sched_items, S_idx_wait=self.S_idx_wait, publish=self.gs_publish,
-                                err=self.gs_err, **kw)
+                                err=self.gs_err, nondep=self.gs_nondep, **kw)
             return
         if not exact_multi and hasattr(self.be, "gs_levels"):
             # no collective between levels: the whole sweep is one C call (one launch per level)

@@ -107,12 +107,13 @@ class HipBackend:
         p.sumr2, p.lambda_eff, p.stat_out = _p(kw.get("sumr2")), _p(kw.get("lambda_eff")), _p(kw.get("stat_out"))
         return p
 
-    def gs_dataflow(self, *, items, S_idx_wait, publish, err, **kw):
+    def gs_dataflow(self, *, items, S_idx_wait, publish, err, nondep=None, **kw):
         """Whole sweep as one persistent launch; see als_gs_sweep_dataflow."""
         p = self._gs_params(items, kw)
         assert publish.shape == kw["V"].shape and publish.is_contiguous()
-        self._check(self.lib.als_gs_sweep_dataflow(C.byref(p), _p(S_idx_wait), _p(publish), publish.shape[0], _p(err),
-                                                   self._stream()), "als_gs_sweep_dataflow")
+        assert nondep is None or (nondep.shape == kw["V"].shape and nondep.is_contiguous())
+        self._check(self.lib.als_gs_sweep_dataflow(C.byref(p), _p(S_idx_wait), _p(publish), publish.shape[0], _p(nondep),
+                                                   _p(err), self._stream()), "als_gs_sweep_dataflow")
 
     def gs_levels(self, *, offsets, **kw):
         """All levels of the sweep with one C call (offsets: host int64 numpy array, nlevels+1)."""

@@ -107,12 +107,13 @@ void k_gs_level(const als_gs_sweep_params P) {
             xr = wave_sum(xr); yy = wave_sum(yy); xx = wave_sum(xx);
             if (lane == 0) {
                 const float sumr = P.sumr[item], sumr2 = P.sumr2[item];
-                const float s1 = sumr - nnz * bnew;
-                const float s2 = sumr2 - 2.f * bnew * sumr + nnz * bnew * bnew;
-                const float cross = xr + (bold - bnew) * dot;
-                const float quad = yy - P.lambda_eff[item] * xx;
-                P.stat_out[2 * i64] = s1 - dot;
-                P.stat_out[2 * i64 + 1] = s2 - 2.f * cross + quad;
+                const double bn = bnew, dt = dot;             // a difference of large sums: combined in double
+                const double s1 = (double)sumr - (double)nnz * bn;
+                const double s2 = (double)sumr2 - 2.0 * bn * (double)sumr + (double)nnz * bn * bn;
+                const double cross = (double)xr + ((double)bold - bn) * dt;
+                const double quad = (double)yy - (double)P.lambda_eff[item] * (double)xx;
+                P.stat_out[2 * i64] = (float)(s1 - dt);
+                P.stat_out[2 * i64 + 1] = (float)(s2 - 2.0 * cross + quad);
             }
         }
     } else {
@@ -203,7 +204,7 @@ struct DfCfg {
 template <int KB, bool STREAM>
 __global__ __launch_bounds__((64 * DfCfg<KB, STREAM>::WPW), (DfCfg<KB, STREAM>::IMAGE ? 1 : 2))
 void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, float* pub,
-                   int32_t* err, int64_t nitems, int nwaves) {
+                   int32_t* err, int64_t nitems, int nwaves, const float* __restrict__ nondep) {
     using C = KCfg<KB>;
     constexpr int KP = C::KP, NR = C::NR;
     using D = DfCfg<KB, STREAM>;
@@ -270,6 +271,10 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
         // as soon as all its words are there.  The order of the floating-point sum never depends on timing:
         // the sweep is bitwise reproducible.
         constexpr int GB = (NR == 1) ? 16 : 8;
+        if (nondep) {           // pass 1 was done for all items in parallel by k_gs_nondep (same sums, same order)
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) g[rr] = nondep[i64 * P.ld + col[rr]];
+        } else
         for (int64_t t0 = s0; t0 < s1; t0 += 64) {
             const int nn = (int)min((int64_t)64, s1 - t0);
             const int raw = (lane < nn) ? Sw[t0 + lane] : item;
@@ -422,20 +427,66 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
             xr = wave_sum(xr); yy = wave_sum(yy); xx = wave_sum(xx);
             if (lane == 0) {
                 const float sumr2 = P.sumr2[item];
-                const float s1v = sumr - nnz * bnew;
-                const float s2v = sumr2 - 2.f * bnew * sumr + nnz * bnew * bnew;
-                const float cross = xr + (bold - bnew) * dot;
-                const float quad = yy - P.lambda_eff[item] * xx;
-                P.stat_out[2 * i64] = s1v - dot;
-                P.stat_out[2 * i64 + 1] = s2v - 2.f * cross + quad;
+                const double bn = bnew, dt = dot;             // a difference of large sums: combined in double
+                const double s1v = (double)sumr - (double)nnz * bn;
+                const double s2v = (double)sumr2 - 2.0 * bn * (double)sumr + (double)nnz * bn * bn;
+                const double cross = (double)xr + ((double)bold - bn) * dt;
+                const double quad = (double)yy - (double)P.lambda_eff[item] * (double)xx;
+                P.stat_out[2 * i64] = (float)(s1v - dt);
+                P.stat_out[2 * i64 + 1] = (float)(s2v - 2.0 * cross + quad);
             }
         }
     }
 }
 
+// Pass 1 of the dataflow sweep for ALL listed items at once: g_i = sum over the neighbours j of i that are NOT
+// dependencies (j > i, or not swept in this call: their rows do not change during the sweep) of S_ij V_j, with
+// exactly the chunking and summation order of the in-sweep loop (64 neighbours per chunk, GB rows in flight,
+// dependency lanes riding along with weight 0) - bitwise the same sums, off the sweep's dependency chain.
+template <int KB>
+__global__ __launch_bounds__(256)
+void k_gs_nondep(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, int64_t nitems, float* __restrict__ out) {
+    using C = KCfg<KB>;
+    constexpr int KP = C::KP, NR = C::NR;
+    const int lane = threadIdx.x & 63;
+    const int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (it >= nitems) return;
+    const int item = P.items[it];
+    const int64_t i64 = item;
+    const int64_t s0 = P.S_ptr[item], s1 = P.S_ptr[item + 1];
+    int col[NR];
+    float g[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) { col[rr] = perm_to_col<KB>(min(lane + 64 * rr, KP - 1)); g[rr] = 0.f; }
+    constexpr int GB = (NR == 1) ? 16 : 8;
+    for (int64_t t0 = s0; t0 < s1; t0 += 64) {
+        const int nn = (int)min((int64_t)64, s1 - t0);
+        const int raw = (lane < nn) ? Sw[t0 + lane] : item;
+        const int sj_l = raw & 0x7fffffff;
+        const float sv_now = (lane < nn && raw >= 0) ? P.S_val[t0 + lane] : 0.f;
+        for (int e0 = 0; e0 < nn; e0 += GB) {
+            float vv[GB][NR], sv[GB];
+#pragma unroll
+            for (int e = 0; e < GB; ++e) {
+                const int sj = __shfl(sj_l, min(e0 + e, 63), 64);
+                sv[e] = (e0 + e < 64) ? __shfl(sv_now, min(e0 + e, 63), 64) : 0.f;
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) vv[e][rr] = P.V[(int64_t)sj * P.ld + col[rr]];
+            }
+#pragma unroll
+            for (int e = 0; e < GB; ++e)
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) g[rr] = fmaf(sv[e], vv[e][rr], g[rr]);
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr)
+        if (lane + 64 * rr < KP) out[i64 * P.ld + col[rr]] = g[rr];
+}
+
 template <int KB, bool STREAM>
 int launch_gs_dataflow_as(const als_gs_sweep_params* p, const int32_t* Sw, float* pub,
-                          int32_t* err, int64_t nitems, hipStream_t st, int* waves_out) {
+                          int32_t* err, int64_t nitems, hipStream_t st, int* waves_out, const float* nondep) {
     // Every wave of the launch must be co-resident (a non-resident workgroup would never start while the
     // resident ones wait for its items): the grid is sized from the occupancy the runtime reports for this
     // kernel - registers and LDS included - times the number of CUs, capped at 8 waves per CU.
@@ -463,23 +514,25 @@ int launch_gs_dataflow_as(const als_gs_sweep_params* p, const int32_t* Sw, float
     if ((int64_t)nwg * WPW > nitems) nwg = (int)((nitems + WPW - 1) / WPW);
     if (nwg < 1) return 0;
     hipLaunchKernelGGL((k_gs_dataflow<KB, STREAM>), dim3(nwg), dim3(64 * WPW), 0, st, *p, Sw, pub, err, nitems,
-                       nwg * WPW);
+                       nwg * WPW, nondep);
     return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
 }
 
 template <int KB>
 int launch_gs_dataflow(const als_gs_sweep_params* p, const int32_t* Sw, float* pub,
-                       int32_t* err, int64_t nitems, hipStream_t st) {
+                       int32_t* err, int64_t nitems, hipStream_t st, float* nondep) {
+    if (nondep && nitems > 0)
+        hipLaunchKernelGGL(k_gs_nondep<KB>, dim3((unsigned)((nitems + 3) / 4)), dim3(256), 0, st, *p, Sw, nitems, nondep);
     if constexpr (KB > 4) {
         // far more items than the image form keeps in flight: the sweep is throughput-bound, stream the factor
         int image_waves = 0;
-        const int rc = launch_gs_dataflow_as<KB, false>(p, Sw, pub, err, nitems, st, &image_waves);
+        const int rc = launch_gs_dataflow_as<KB, false>(p, Sw, pub, err, nitems, st, &image_waves, nondep);
         if (rc != 0) return rc;
         static const char* force = getenv("ALS_GS_FORM");           // "stream" / "image": tests and experiments
         const bool stream = force ? (force[0] == 's') : nitems > (int64_t)256 * image_waves;
-        if (stream) return launch_gs_dataflow_as<KB, true>(p, Sw, pub, err, nitems, st, nullptr);
+        if (stream) return launch_gs_dataflow_as<KB, true>(p, Sw, pub, err, nitems, st, nullptr, nondep);
     }
-    return launch_gs_dataflow_as<KB, false>(p, Sw, pub, err, nitems, st, nullptr);
+    return launch_gs_dataflow_as<KB, false>(p, Sw, pub, err, nitems, st, nullptr, nondep);
 }
 
 template <int KB>
@@ -494,7 +547,7 @@ int launch_gs(const als_gs_sweep_params* p, hipStream_t st) {
 }  // namespace
 
 extern "C" int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t* S_idx_wait, float* publish,
-                                     int64_t nrows, int32_t* err, void* stream) {
+                                     int64_t nrows, float* nondep, int32_t* err, void* stream) {
     if (!p || !S_idx_wait || !publish || !err || nrows < 0) return ALS_E_BADARG;
     const int ld = als_padded_k(p->k);
     if (ld < 0) return ALS_E_BADK;
@@ -507,16 +560,16 @@ extern "C" int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t
         hipMemsetD32Async((hipDeviceptr_t)publish, (int)GS_SENTINEL, (size_t)nrows * ld, st) != hipSuccess)
         return ALS_E_LAUNCH;
     switch (ld / 16) {
-        case 1: return launch_gs_dataflow<1>(p, S_idx_wait, publish, err, p->nitems, st);
-        case 2: return launch_gs_dataflow<2>(p, S_idx_wait, publish, err, p->nitems, st);
-        case 3: return launch_gs_dataflow<3>(p, S_idx_wait, publish, err, p->nitems, st);
-        case 4: return launch_gs_dataflow<4>(p, S_idx_wait, publish, err, p->nitems, st);
-        case 5: return launch_gs_dataflow<5>(p, S_idx_wait, publish, err, p->nitems, st);
-        case 6: return launch_gs_dataflow<6>(p, S_idx_wait, publish, err, p->nitems, st);
-        case 7: return launch_gs_dataflow<7>(p, S_idx_wait, publish, err, p->nitems, st);
-        case 8: return launch_gs_dataflow<8>(p, S_idx_wait, publish, err, p->nitems, st);
-        case 9: return launch_gs_dataflow<9>(p, S_idx_wait, publish, err, p->nitems, st);
-        case 10: return launch_gs_dataflow<10>(p, S_idx_wait, publish, err, p->nitems, st);
+        case 1: return launch_gs_dataflow<1>(p, S_idx_wait, publish, err, p->nitems, st, nondep);
+        case 2: return launch_gs_dataflow<2>(p, S_idx_wait, publish, err, p->nitems, st, nondep);
+        case 3: return launch_gs_dataflow<3>(p, S_idx_wait, publish, err, p->nitems, st, nondep);
+        case 4: return launch_gs_dataflow<4>(p, S_idx_wait, publish, err, p->nitems, st, nondep);
+        case 5: return launch_gs_dataflow<5>(p, S_idx_wait, publish, err, p->nitems, st, nondep);
+        case 6: return launch_gs_dataflow<6>(p, S_idx_wait, publish, err, p->nitems, st, nondep);
+        case 7: return launch_gs_dataflow<7>(p, S_idx_wait, publish, err, p->nitems, st, nondep);
+        case 8: return launch_gs_dataflow<8>(p, S_idx_wait, publish, err, p->nitems, st, nondep);
+        case 9: return launch_gs_dataflow<9>(p, S_idx_wait, publish, err, p->nitems, st, nondep);
+        case 10: return launch_gs_dataflow<10>(p, S_idx_wait, publish, err, p->nitems, st, nondep);
     }
     return ALS_E_BADK;
 }

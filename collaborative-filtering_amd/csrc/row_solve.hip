@@ -705,12 +705,15 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
         xr = wave_sum(xr); yy = wave_sum(yy); xx = wave_sum(xx);
         if (lane == 0) {
             // rhs0 was formed with the old bias (bold)
-            const float s1 = sumr - nnz * bnew;
-            const float s2 = sumr2 - 2.f * bnew * sumr + nnz * bnew * bnew;
-            const float cross = xr + (bold - bnew) * dot;
-            const float quad = yy - lam * xx;
-            P.stat_out[2 * r64] = s1 - dot;
-            P.stat_out[2 * r64 + 1] = s2 - 2.f * cross + quad;
+            // the combination is a difference of large sums: in double (the inputs are fp32 sums; K1-f64 is the
+            // mode for fits whose residuals are ~1e-4 of the ratings)
+            const double bn = bnew, dt = dot;
+            const double s1 = (double)sumr - (double)nnz * bn;
+            const double s2 = (double)sumr2 - 2.0 * bn * (double)sumr + (double)nnz * bn * bn;
+            const double cross = (double)xr + ((double)bold - bn) * dt;
+            const double quad = (double)yy - (double)lam * (double)xx;
+            P.stat_out[2 * r64] = (float)(s1 - dt);
+            P.stat_out[2 * r64 + 1] = (float)(s2 - 2.0 * cross + quad);
         }
     }
 }

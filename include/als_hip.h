@@ -198,12 +198,15 @@ int als_gs_sweep(const als_gs_sweep_params* p, void* stream);
  * items in (level, id) order (p->nitems of them).  S_idx_wait is p->S_idx with the sign bit set on
  * every edge (i -> j) that item i must wait for (j < i and j swept in this call).  publish: scratch
  * [nrows][ld] floats (nrows = rows of p->V); the call resets it and the kernel hands solved rows from
- * producer to consumer through it (each word doubles as its own "ready" flag).  err: int32[1], the caller
+ * producer to consumer through it (each word doubles as its own "ready" flag).  nondep: optional scratch
+ * [nrows][ld]: when given, the neighbour sums that do not depend on the sweep (edges without the wait flag) are
+ * formed for all items by one parallel launch before the persistent one - same sums, same order, off the
+ * dependency chain.  err: int32[1], the caller
  * zeroes it once; set to 1 when a dependency wait exceeded its bound (~40 ms: the launch was not resident as a
  * whole because something else held compute units).  Results are then invalid and the caller should redo the
  * sweep - from the state before it - with als_gs_sweep_levels, which has no residency requirement. */
 int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t* S_idx_wait, float* publish,
-                          int64_t nrows, int32_t* err, void* stream);
+                          int64_t nrows, float* nondep, int32_t* err, void* stream);
 
 /* Whole sweep in one call: level l covers p->items[level_offsets[l] .. level_offsets[l+1]) (host
  * array of nlevels+1 offsets into the device array p->items; p->nitems is ignored).  One launch per
