@@ -611,10 +611,15 @@ class _Engine:
                 self.S_idx_wait = wait_dev
                 self.gs_publish = torch.empty(n_pad, self.ld, dtype=f32, device=device)       # same shape as V
                 self.gs_err = torch.zeros(1, dtype=torch.int32, device=device)
-                # neighbour sums that do not depend on the sweep, formed for all items at once before it
-                # (ALS_GS_NONDEP=0: inside the sweep, as in round 1)
+                # Neighbour sums that do not depend on the sweep can be formed for all items by a parallel launch
+                # before it (same sums, same order).  On graphs without hubs the in-sweep gather hides behind the
+                # dependency waits and the extra launch only costs (cfg 4, sampled graph: 1.79 vs 1.46 ms); with hub
+                # rows it pays (exact top-50 graph, rows of up to 3700 neighbours: 2.43 vs 2.75 ms).  Default: on
+                # when the longest row of S has 1024 neighbours or more; ALS_GS_NONDEP=0 / 1 forces it.
+                nd_env = os.environ.get("ALS_GS_NONDEP")
+                hubs = bool(ptr.size > 1 and int(np.diff(ptr).max()) >= 1024)
                 self.gs_nondep = (torch.empty(n_pad, self.ld, dtype=f32, device=device)
-                                  if os.environ.get("ALS_GS_NONDEP", "1") != "0" else None)
+                                  if (nd_env == "1" or (nd_env is None and hubs)) else None)
         # By-products of the V-step exist for this rank's items only ([ib, ie): n / world rows instead of n - the
         # item Grams and Cholesky factors are n * ld^2 floats each, 65 GB at BASELINE configs[4]); the kernels index
         # them with absolute item ids through a shifted base pointer (_RowShift).  The numpy stand-in of the CPU

@@ -102,10 +102,32 @@ def test_fallback_paths_and_argument_checks():
     assert lib.als_topk_similarity(16, 16, 3, None, 5, None, None, None, None) < 0
 
 
+def _topk_lists(torch, lib, X, topk, dev):
+    """Directed top-k lists straight from als_topk_similarity (what als_graph_classify symmetrises)."""
+    import ctypes as C
+    Xd = torch.as_tensor(np.asarray(X.cpu() if torch.is_tensor(X) else X, dtype=np.float32), device=dev)
+    n, d = Xd.shape
+    Xnd = Xd / (torch.sqrt((Xd * Xd).sum(1, keepdim=True)) + np.float32(1e-8))
+    ns = next(v for v in (1, 2, 4, 5, 8, 16) if 4 * v >= d)
+    n_pad = 16 * ((n + 15) // 16)
+    XT = torch.zeros(n_pad, 4 * ns, dtype=torch.float32, device=dev)
+    XT[:n, :d] = Xnd
+    XT = XT.view(n_pad, ns, 4).permute(1, 0, 2).contiguous()
+    tv = torch.empty(n, topk, dtype=torch.float32, device=dev)
+    ti = torch.empty(n, topk, dtype=torch.int32, device=dev)
+    tc = torch.empty(n, dtype=torch.int32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
+    assert lib.als_topk_similarity(n, n_pad, ns, p(XT), topk, p(tv), p(ti), p(tc), None) == 0
+    torch.cuda.synchronize()
+    return tv.cpu().numpy(), ti.cpu().numpy(), tc.cpu().numpy()
+
+
 def test_product_graph_at_the_cfg4_item_count():
     """n = 100 000 items (BASELINE configs[3]) through the product entry point, on bench.py's graph features
-    (19 genre-like binary columns + a small continuous column): the exact top-50 over ALL items.  Sampled rows
-    are checked against float64 similarities computed on the host for those rows."""
+    (19 genre-like binary columns + a small continuous column): the exact top-50 over ALL items.  For sampled rows
+    the selected neighbours are checked against float64 similarities computed on the host (popular genre patterns
+    have thousands of neighbours within 1e-7 of each other: what is required is that nothing clearly better was
+    left out), and the CSR is the max-symmetrisation of the lists."""
     torch, layout, lib, dev = _env()
     import bench
     n, topk = 100_000, 50
@@ -114,28 +136,25 @@ def test_product_graph_at_the_cfg4_item_count():
     ptr_h, idx_h, val_h = ptr.cpu().numpy(), idx.cpu().numpy(), val.cpu().numpy()
     deg = np.diff(ptr_h)
     assert deg.min() >= 1 and deg.mean() > topk and idx_h.size == ptr_h[-1]
+    tv, ti, tc = _topk_lists(torch, lib, X, topk, dev)
+    assert np.all(tc == topk)
     Xh = X.cpu().numpy().astype(np.float64)
     Xn = Xh / (np.sqrt((Xh * Xh).sum(1, keepdims=True)) + 1e-8)
     rng = np.random.default_rng(3)
-    rich = np.flatnonzero((Xh[:, :19] != 0).sum(1) >= 2)           # items without genres have ~n near-tied neighbours
-    for i in rng.choice(rich, size=20, replace=False):
+    for i in rng.integers(0, n, size=24):
         s = Xn @ Xn[i]
         s[i] = 0.0
-        want = np.argsort(-s, kind="stable")[:topk]
-        want = want[s[want] != 0.0]
-        # among 10^5 candidates the boundary can hold near-ties that fp32 (kernel) and fp64 (here) order
-        # differently: everything clearly above the boundary value must be there
-        want = want[s[want] > s[want[-1]] + 2e-6]
+        tau = np.sort(s)[-topk]                                     # 50th largest in float64
+        li, lv = ti[i], tv[i]
+        assert len(set(li.tolist())) == topk
+        np.testing.assert_allclose(lv, s[li], rtol=0, atol=2e-6)
+        assert s[li].min() >= tau - 2e-6                            # only (near-)top entries were taken ...
+        assert (s > tau + 2e-6).sum() == np.isin(np.flatnonzero(s > tau + 2e-6), li).sum()   # ... and no clearly better one left out
         row = idx_h[ptr_h[i]:ptr_h[i + 1]]
-        assert want.size >= topk // 2 and np.isin(want, row).all()   # own top-k (the rest are mirrored entries)
-        pos = np.searchsorted(row, want)
-        np.testing.assert_allclose(val_h[ptr_h[i]:ptr_h[i + 1]][pos], s[want], rtol=0, atol=2e-6)
-        # every mirrored entry j of row i has i among j's own top-k
-        own50 = np.argsort(-s, kind="stable")[:topk + 5]
-        for j in np.setdiff1d(row, own50)[:5]:
-            sj = Xn @ Xn[j]
-            sj[j] = 0.0
-            assert i in np.argsort(-sj, kind="stable")[:topk + 5]
+        own = li[lv != 0.0]
+        assert np.isin(own, row).all()                              # the row holds its own list ...
+        for j in np.setdiff1d(row, own)[:5]:                        # ... and mirrors of lists that contain i
+            assert i in ti[j]
     # symmetric: the transposed pattern is the pattern
     rows = np.repeat(np.arange(n), deg)
     key = rows * n + idx_h

@@ -393,6 +393,25 @@ def test_hip_graph_replay_is_bitwise_the_eager_fit(name):
         np.testing.assert_array_equal(a.W[f], b.W[f])
 
 
+@pytest.mark.parametrize("name,k", [("g5_graph_a0.5", None), ("g10_full_k128", None)])
+def test_nondep_prepass_is_bitwise_the_in_sweep_gather(name, k, monkeypatch):
+    """The neighbour sums that do not depend on the sweep are formed by a parallel launch before the persistent
+    one (k_gs_nondep) with the chunking and summation order of the in-sweep loop: bitwise the same fit."""
+    _cuda()
+    g = Golden(name)
+    r, c, v = g.train
+    kw = dict(features=g.features or None, tol=None, verbose=0)
+    monkeypatch.setenv("ALS_GS_NONDEP", "1")
+    a = _model_for(g).fit_coo(r, c, v, (g.m, g.n), **kw)
+    assert a._eng.gs_nondep is not None
+    monkeypatch.setenv("ALS_GS_NONDEP", "0")
+    b = _model_for(g).fit_coo(r, c, v, (g.m, g.n), **kw)
+    assert b._eng.gs_nondep is None
+    np.testing.assert_array_equal(a.V, b.V)
+    np.testing.assert_array_equal(a.U, b.U)
+    np.testing.assert_array_equal(a.history["train_rmse"], b.history["train_rmse"])
+
+
 def test_hip_graph_replay_over_many_iterations():
     """30 iterations with features (W-step every 5th) and the Laplacian: the W-step / no-W-step graphs are replayed
     alternately many times, with no host read-back in between (tol=None).  Bitwise the eager fit."""
