@@ -17,7 +17,7 @@ SPLIT_CHUNK = 4096          # ALS_SPLIT_CHUNK
 MAX_K = 160                 # ALS_MAX_K
 
 EXPORTS = ("als_version", "als_padded_k", "als_perm_index", "als_partial_slot_bytes", "als_partial_slot_bytes_f64",
-           "als_row_solve", "als_gs_sweep", "als_gs_sweep_levels", "als_gs_sweep_dataflow", "als_residual_stats", "als_w_normal_equations", "als_spd_solve_workspace_bytes", "als_spd_solve_f64", "als_item_stats", "als_sum_pairs", "als_sumsq_partials",
+           "als_row_solve", "als_row_solve_scratch_bytes", "als_gs_sweep", "als_gs_sweep_levels", "als_gs_sweep_dataflow", "als_residual_stats", "als_w_normal_equations", "als_spd_solve_workspace_bytes", "als_spd_solve_f64", "als_item_stats", "als_sum_pairs", "als_sumsq_partials",
            "als_sumsq", "als_history_row", "als_compose_z", "als_predict_at", "als_predict_dense",
            "als_topk_similarity", "als_graph_classify",
            "als_host_coo_to_sides", "als_host_row_tasks", "als_host_level_schedule")
@@ -39,7 +39,7 @@ class RowSolveParams(C.Structure):
         ("rhs_out", _vp), ("colsum_out", _vp), ("sumr_out", _vp), ("sumr2_out", _vp), ("stat_out", _vp),
         ("status", _vp),
         ("tasks", _vp), ("ntasks", _i64), ("long_rows", _vp), ("nlong", _i64),
-        ("workspace", _vp),
+        ("workspace", _vp), ("scratch", _vp),
     ]
 
 
@@ -95,6 +95,8 @@ def load():
     lib.als_partial_slot_bytes_f64.argtypes = [C.c_int]
     lib.als_partial_slot_bytes_f64.restype = _i64
     lib.als_row_solve.argtypes = [C.POINTER(RowSolveParams), _vp]
+    lib.als_row_solve_scratch_bytes.argtypes = [C.c_int]
+    lib.als_row_solve_scratch_bytes.restype = _i64
     lib.als_gs_sweep.argtypes = [C.POINTER(GsSweepParams), _vp]
     lib.als_gs_sweep_levels.argtypes = [C.POINTER(GsSweepParams), _vp, _i64, _vp]
     lib.als_gs_sweep_dataflow.argtypes = [C.POINTER(GsSweepParams), _vp, _vp, _i64, _vp, _vp, _vp]
@@ -117,7 +119,8 @@ def load():
     lib.als_host_row_tasks.argtypes = [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]
     lib.als_host_level_schedule.argtypes = [_i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]
     for name in EXPORTS:
-        if name not in ("als_partial_slot_bytes", "als_partial_slot_bytes_f64", "als_spd_solve_workspace_bytes"):
+        if name not in ("als_partial_slot_bytes", "als_partial_slot_bytes_f64", "als_spd_solve_workspace_bytes",
+                        "als_row_solve_scratch_bytes"):
             getattr(lib, name).restype = C.c_int
     lib.als_spd_solve_workspace_bytes.restype = C.c_size_t
     _lib = lib

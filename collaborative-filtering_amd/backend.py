@@ -44,6 +44,10 @@ class HipBackend:
                                            device=device)
         self._stats_partials: Optional[torch.Tensor] = None
         self._spd_ws: Optional[torch.Tensor] = None
+        self._row_scratch: dict = {}       # k -> scratch of the two-waves-per-row kernel (als_row_solve_scratch_bytes)
+        # ALS_ROW_PAIR=1: k = 97 ... 128 on the two-waves-per-row kernel (row_pair.hip).  Measured slower than one
+        # wave per row on short rows and equal on long ones, so it is opt-in
+        self.row_pair = os.environ.get("ALS_ROW_PAIR", "0") == "1"
         self.ablate = int(os.environ.get("ALS_ABLATE", "0"))   # phase ablation of als_row_solve (profiles/ablate.sh)
 
     # -- helpers -------------------------------------------------------------
@@ -81,7 +85,18 @@ class HipBackend:
         p.ndual_mid = int(getattr(tasks, "nmid", 0))
         p.long_rows, p.nlong = _p(tasks.long_rows), tasks.nlong
         p.workspace = _p(workspace)
+        p.scratch = _p(self._scratch_for(k))
         self._check(self.lib.als_row_solve(C.byref(p), self._stream()), "als_row_solve")
+
+    def _scratch_for(self, k: int) -> Optional[torch.Tensor]:
+        """Scratch of als_row_solve for k factors: one per backend, calls on one stream run in order."""
+        if not self.row_pair or self.ablate:
+            return None
+        if k not in self._row_scratch:
+            nbytes = int(self.lib.als_row_solve_scratch_bytes(k))
+            self._row_scratch[k] = (torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+                                    if nbytes > 0 else None)
+        return self._row_scratch[k]
 
     # -- K2 ------------------------------------------------------------------
     def gs_level(self, *, k, ld, items, S_ptr, S_idx, S_val, alpha, factor, rhs, colsum, sumr,

@@ -24,6 +24,9 @@
 #include <type_traits>
 #include "als_device.hpp"
 #include "als_hip.h"
+#include "row_common.hpp"
+
+int als_row_pair_dispatch(const als_row_solve_params* p, hipStream_t st);          // row_pair.hip
 
 namespace {
 
@@ -42,8 +45,6 @@ struct RowAcc {
         sumr = 0.f; sumr2 = 0.f;
     }
 };
-
-__host__ __device__ constexpr int blk_idx(int I, int K) { return I * (I + 1) / 2 + K; }
 
 // ---------------------------------------------------------------------------
 // 64 ratings: lane t holds (off_l, r_l) of rating t; 16 steps of 4 ratings.
@@ -100,28 +101,6 @@ __device__ __forceinline__ void process_chunk(RowAcc<KB>& A, int off_l, float r_
 // arithmetic is the VALU's share.  Lane (c,q) now takes ratings 8q..8q+7 of a 32-rating
 // group: the 8 values it loads per block are exactly its 8 k-elements of the A/B operand.
 // ---------------------------------------------------------------------------
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ int pack_hi16(float hi_src, float lo_src) {     // {hi_src[31:16], lo_src[31:16]}
-    return __builtin_amdgcn_perm(__float_as_int(hi_src), __float_as_int(lo_src), 0x07060302);
-}
-
-// exact 3-way bf16 split of two floats (see process_chunk_bf16x3): packed high halves of x, of r = x - h and of
-// l = r - m.  (v_dot2c_f32_bf16 with a (-1, 0) constant on the packed word would form a remainder in one
-// instruction instead of v_and + v_sub; on gfx950 it did NOT reproduce the remainders bit for bit and issues at
-// half rate with three waves per SIMD - profiles/ubench/split_dot2c.hip, profiles/r02_ubench_split_dot2c.txt.)
-__device__ __forceinline__ void split3(float x0, float x1, int& H, int& M, int& L) {
-    H = pack_hi16(x1, x0);
-    const float h0 = __int_as_float(__float_as_int(x0) & 0xFFFF0000);
-    const float h1 = __int_as_float(__float_as_int(x1) & 0xFFFF0000);
-    const float r0 = x0 - h0, r1 = x1 - h1;                       // exact
-    M = pack_hi16(r1, r0);
-    const float m0 = __int_as_float(__float_as_int(r0) & 0xFFFF0000);
-    const float m1 = __int_as_float(__float_as_int(r1) & 0xFFFF0000);
-    const float l0 = r0 - m0, l1 = r1 - m1;                       // exact, <= 8 significant bits
-    L = pack_hi16(l1, l0);
-}
 
 template <int KB, bool FULL>
 __device__ __forceinline__ void process_chunk_bf16x3(RowAcc<KB>& A, int off_l, float r_l, int nvalid,
@@ -348,46 +327,6 @@ __device__ __forceinline__ void add_partial(RowAcc<KB>& A, const float* __restri
     A.sumr2 += ws[it * 64 + lane];
 }
 
-// ---------------------------------------------------------------------------
-// blocked Cholesky state of one wave
-// ---------------------------------------------------------------------------
-template <int KB>
-struct Chol {
-    static constexpr int NR = KCfg<KB>::NR;
-    float di[NR];       // 1 / L[i][i] of the lane's rows i = lane + 64*rr
-    float y[NR];        // forward-solved right-hand side (when SOLVE)
-    float b[NR];        // running right-hand side
-};
-
-// positive definiteness, checked once after the factorisation: pivot d <= 0 (or NaN) leaves rsq(d) = inf / NaN
-// in di, and everything computed after it is NaN as well - no per-pivot compare needed
-template <int KB>
-__device__ __forceinline__ bool chol_spd(const Chol<KB>& S, int lane) {
-    bool bad = false;
-#pragma unroll
-    for (int rr = 0; rr < KCfg<KB>::NR; ++rr) {
-        const float v = S.di[rr];
-        bad = bad || ((lane + 64 * rr < KCfg<KB>::KP) && !(v > 0.f && v < __builtin_inff()));
-    }
-    return __builtin_amdgcn_ballot_w64(bad) == 0;
-}
-
-// one pivot of panel J (column 16J + T): scale the column, ride the forward
-// substitution along, update the remaining columns of the panel
-// p[.][t2] += l * (-L[16J+t2][T]) for t2 = T2 ... 15; the negated multiplier is lane t2 of every 16-lane row of
-// lrep and is picked up by the FMA itself (v_fmac_f32_dpp row_newbcast:t2).  The compiler only emits DPP on
-// v_mov here (its DPP combiner has no VOP3 v_fma form on gfx9), so the VOP2 form is written out; the caller
-// orders an s_nop between the write of lrep and these reads (wait states the hazard recogniser cannot see).
-template <int KB, int T2>
-__device__ __forceinline__ void panel_trailing(float (&p)[KCfg<KB>::NR][16], const float (&l)[KCfg<KB>::NR], float lrep) {
-    if constexpr (T2 < 16) {
-#pragma unroll
-        for (int rr = 0; rr < KCfg<KB>::NR; ++rr)
-            asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                : "+v"(p[rr][T2]) : "v"(lrep), "v"(l[rr]), "n"(T2));
-        panel_trailing<KB, T2 + 1>(p, l, lrep);
-    }
-}
 template <int KB, int J, int T, bool SOLVE>
 __device__ __forceinline__ void panel_pivot(float (&p)[KCfg<KB>::NR][16], Chol<KB>& S, int lane) {
     constexpr int NR = KCfg<KB>::NR;
@@ -504,65 +443,6 @@ __device__ __forceinline__ void chol_panels(RowAcc<KB>& A, Chol<KB>& S, float* _
         chol_panel<KB, J, SOLVE>(A, S, Ls, lane);
         chol_panels<KB, J + 1, SOLVE>(A, S, Ls, lane);
     }
-}
-
-// coefficients of one 16-step block of the transposed solve: cf[rr][t] = L[16 pb + t][i] / L[i][i] for the
-// lanes i = lane + 64 rr below the pivot row, 0 elsewhere (compile-time lane masks)
-template <int KB, int RR, int T, int PB>
-__device__ __forceinline__ void bwd_coeff_one(const float* __restrict__ Ls, const int (&colbase)[KCfg<KB>::NR][4],
-                                              const Chol<KB>& S, float (&cf)[KCfg<KB>::NR][16]) {
-    constexpr int prow = 16 * PB + T;
-    const float v = Ls[colbase[RR][(T >> 2) & 3] + prow * 16];
-    cf[RR][T] = select_lanes<lanes_below<prow, RR>()>(v * S.di[RR], 0.f);
-    if constexpr (T + 1 < 16) bwd_coeff_one<KB, RR, T + 1, PB>(Ls, colbase, S, cf);
-    else if constexpr (RR + 1 < KCfg<KB>::NR) bwd_coeff_one<KB, RR + 1, 0, PB>(Ls, colbase, S, cf);
-}
-template <int KB, int PB0>
-__device__ __forceinline__ void bwd_coeffs(const float* __restrict__ Ls, const int (&colbase)[KCfg<KB>::NR][4],
-                                           const Chol<KB>& S, float (&cf)[KCfg<KB>::NR][16],
-                                           std::integral_constant<int, PB0>, int pb) {
-    // pb is a compile-time constant at every call site (unrolled loop); dispatch it to the template
-    if (pb == PB0) bwd_coeff_one<KB, 0, 0, PB0>(Ls, colbase, S, cf);
-    else if constexpr (PB0 + 1 < KB) bwd_coeffs<KB>(Ls, colbase, S, cf, std::integral_constant<int, PB0 + 1>{}, pb);
-}
-
-// L^T x = y with L in LDS (block columns).  Lane (+64 rr) owns unknown i = lane + 64 rr and
-// reads its column L[p][i], p > i, 16 rows at a time.
-template <int KB>
-__device__ __forceinline__ void backward_solve(const float* __restrict__ Ls, const Chol<KB>& S,
-                                               float (&x)[KCfg<KB>::NR], int lane) {
-    using C = KCfg<KB>;
-    constexpr int KP = C::KP, NR = C::NR;
-    const int c = lane & 15;
-    float rs[NR];
-    int colbase[NR][4];
-#pragma unroll
-    for (int rr = 0; rr < NR; ++rr) {
-        const int i = min(lane + 64 * rr, KP - 1);
-        const int Ji = i >> 4;
-        rs[rr] = S.y[rr] * S.di[rr];
-        // element (row, lane's column) of the lane's block column sits at base[g] + row * 16, g = (row >> 2) & 3
-        // selecting the swizzled 4-float group.  Rows above the block column (row < 16 Ji) are masked
-        // below; their addresses stay inside this wave's image (lcol_off(J) >= 256 J), so the read needs
-        // no clamp and every address is one of four per-lane bases plus a compile-time offset.
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            colbase[rr][g] = C::lcol_off_rt(Ji) - 16 * Ji * 16 + (c & 3) + (((c >> 2) ^ g) << 2);
-    }
-#pragma unroll
-    for (int pb = KB - 1; pb >= 0; --pb) {
-        float cf[NR][16];
-        bwd_coeffs<KB>(Ls, colbase, S, cf, std::integral_constant<int, 0>{}, pb);
-#pragma unroll
-        for (int t = 15; t >= 0; --t) {
-            const int prow = 16 * pb + t;
-            const float xi = readlane_f(rs[prow >> 6], prow & 63);
-#pragma unroll
-            for (int rr = 0; rr < NR; ++rr) rs[rr] = fmaf(-cf[rr][t], xi, rs[rr]);
-        }
-    }
-#pragma unroll
-    for (int rr = 0; rr < NR; ++rr) x[rr] = rs[rr];
 }
 
 // ---------------------------------------------------------------------------
@@ -999,7 +879,11 @@ int launch_row_solve(const als_row_solve_params* p, hipStream_t st) {
         als_row_solve_params q = *p;
         q.ntasks = nprimal;
         const unsigned grid = (unsigned)((nprimal + C::WPW - 1) / C::WPW);
-        if (p->gram_mode == ALS_GRAM_BF16X3)
+        if ((KB == 7 || KB == 8) && p->gram_mode == ALS_GRAM_BF16X3 && p->reserved0 == 0 && p->scratch) {
+            // k = 112 / 128: two waves per row (row_pair.hip)
+            const int rc = als_row_pair_dispatch(&q, st);
+            if (rc != 0) return rc;
+        } else if (p->gram_mode == ALS_GRAM_BF16X3)
             hipLaunchKernelGGL((k_row_tasks<KB, 1>), dim3(grid), dim3(64 * C::WPW), 0, st, q);
         else
             hipLaunchKernelGGL((k_row_tasks<KB, 0>), dim3(grid), dim3(64 * C::WPW), 0, st, q);

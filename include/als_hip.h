@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ALS_HIP_VERSION 100
+#define ALS_HIP_VERSION 101
 
 #define ALS_E_BADARG   (-1)
 #define ALS_E_BADK     (-2)   /* k outside 1..ALS_MAX_K */
@@ -163,9 +163,16 @@ typedef struct als_row_solve_params {
     const als_task*     tasks;      int64_t ntasks;
     const als_long_row* long_rows;  int64_t nlong;
     void*          workspace;
+    void*          scratch;             /* nullable: als_row_solve_scratch_bytes(k) bytes, contents irrelevant, must not be
+                                           shared by calls that may run concurrently.  When given (and the call is
+                                           a bf16x3 one without ablation flags) k = 97 ... 128 runs on the
+                                           two-waves-per-row kernel (row_pair.hip), which keeps the running totals of
+                                           rows longer than 512 ratings there; NULL = one wave per row */
 } als_row_solve_params;
 
 int als_row_solve(const als_row_solve_params* p, void* stream);
+/* size of als_row_solve_params::scratch for k factors; 0 = not used for this k */
+int64_t als_row_solve_scratch_bytes(int k);
 
 /* ---------------------------------------------------------------------------
  * als_gs_sweep - one level of the Gauss-Seidel Laplacian sweep.
