@@ -1,10 +1,13 @@
-"""Item-feature normalisation - host-side mirror of the reference's
+"""Item-feature normalisation - mirror of the reference's
 `scripts/prepare_features.py` (`normalize_feature` :131-201, `normalize_features_dict` :204-233).
 
-Same names, arguments, defaults and error behaviour; the arithmetic is numpy in the input's dtype
-followed by ONE cast to `dtype` (float32 by default - the dtype the fit's HBM layout stores features
-in).  O(n d), runs once per dataset: plumbing around the hot path, deliberately not a kernel.
-Pinned by fixtures generated from the unmodified reference (`tests/golden/feat_norm_*.npz`).
+Same names, arguments, defaults and error behaviour.  Two paths:
+  * host (`normalize_feature`, `normalize_features_dict`): numpy in the input's dtype followed by ONE cast to
+    `dtype` - any dtype, no GPU needed;
+  * device (`normalize_feature_device`, or `device=` on the dict form): float64 input, float32 result left in
+    HBM as a torch tensor, arithmetic in the kernels of csrc/features.hip (`als_normalize_features`), which sum
+    in numpy's order - results are bitwise those of the reference (tests/test_gpu_features.py).
+Both are pinned by fixtures generated from the unmodified reference (`tests/golden/feat_norm_*.npz`).
 """
 from __future__ import annotations
 
@@ -78,12 +81,82 @@ def normalize_feature(X: np.ndarray, method: str = "none", *, impute: str = "non
     return (X if fn is None else fn(X, eps)).astype(dtype, copy=False)
 
 
+_METHOD_CODES = {"none": 0, "row_l1": 1, "row_l2": 2, "col_zscore": 3, "col_minmax": 4}
+
+
+def _fill_with_col_median_device(X):
+    """Device form of `_fill_with_col_median`: the median of a column's finite entries is the middle of its
+    sorted finite entries (mean of the two middle ones for an even count, as numpy's), 0 for an empty column."""
+    import torch
+    bad = ~torch.isfinite(X)
+    if not bool(bad.any()):
+        return X
+    n = X.shape[0]
+    srt = torch.sort(torch.where(bad, torch.full_like(X, float("nan")), X), dim=0).values    # NaN sorts last
+    cnt = n - bad.sum(dim=0)
+    lo = torch.clamp((cnt - 1) // 2, min=0)
+    hi = torch.clamp(cnt // 2, min=0, max=n - 1)
+    med = (srt.gather(0, lo[None, :]) + srt.gather(0, hi[None, :]))[0] / 2.0
+    med = torch.where(cnt > 0, med, torch.zeros_like(med))
+    return torch.where(bad, med[None, :].expand_as(X), X)
+
+
+def normalize_feature_device(X, method: str = "none", *, impute: str = "none", eps: float = DEFAULT_EPS,
+                             device="cuda:0"):
+    """`normalize_feature` on the GPU: X (n_items,) or (n_items, d) float64 (numpy array or torch tensor) ->
+    float32 torch tensor (n_items, d) on `device`.  Same methods, imputation and errors as the host form.
+    (`ALS.fit` takes host arrays: hand it `.cpu().numpy()` of the result.)"""
+    import ctypes as C
+
+    import torch
+
+    from . import _hip
+    if method not in _METHODS:
+        raise ValueError(f"Unknown method '{method}'.")
+    if impute not in ("none", "col_median"):
+        raise ValueError(f"Unknown impute '{impute}'.")
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("normalize_feature_device needs a ROCm device; use normalize_feature on the host")
+    Xt = torch.from_numpy(np.ascontiguousarray(X)) if isinstance(X, np.ndarray) else X
+    if Xt.dtype != torch.float64:
+        raise TypeError("the device path computes in float64 like the reference does on float64 input; "
+                        f"got {Xt.dtype} (use normalize_feature for other dtypes)")
+    Xt = Xt.reshape(-1, 1) if Xt.dim() == 1 else Xt
+    Xt = Xt.to(dev).contiguous()
+    lib = _hip.load()
+    with torch.cuda.device(dev):
+        if impute == "col_median":
+            Xt = _fill_with_col_median_device(Xt).contiguous()
+        n, d = Xt.shape
+        out = torch.empty(n, d, dtype=torch.float32, device=dev)
+        work = torch.empty(2 * d, dtype=torch.float64, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        rc = lib.als_normalize_features(n, d, C.c_void_p(Xt.data_ptr()), _METHOD_CODES[method], float(eps),
+                                        C.c_void_p(out.data_ptr()), C.c_void_p(work.data_ptr()),
+                                        C.c_void_p(status.data_ptr()),
+                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"als_normalize_features failed with status {rc}")
+        if int(status.item()) & 1:
+            raise ValueError("Input feature contains NaN/Inf and impute='none'.")
+    return out
+
+
 def normalize_features_dict(features: Mapping[str, np.ndarray], *, method: str = "none", impute: str = "none",
                             eps: float = DEFAULT_EPS, dtype: str = DEFAULT_DTYPE, copy: bool = True,
-                            per_feature_overrides: Optional[Mapping[str, Mapping[str, Any]]] = None
-                            ) -> Dict[str, np.ndarray]:
-    """`normalize_feature` over a {name: array} dict with shared defaults and per-feature overrides."""
+                            per_feature_overrides: Optional[Mapping[str, Mapping[str, Any]]] = None,
+                            device=None) -> Dict[str, Any]:
+    """`normalize_feature` over a {name: array} dict with shared defaults and per-feature overrides.
+    device (extra, keyword-only): a ROCm device -> every feature through `normalize_feature_device`
+    (float32 tensors in HBM; `dtype` / `copy` do not apply)."""
     shared = dict(method=method, impute=impute, eps=eps, dtype=dtype, copy=copy)
     overrides = per_feature_overrides or {}
+    if device is not None:
+        out = {}
+        for name, X in features.items():
+            kw = {**shared, **dict(overrides.get(name, {}))}
+            out[name] = normalize_feature_device(X, kw["method"], impute=kw["impute"], eps=kw["eps"], device=device)
+        return out
     return {name: normalize_feature(X, **{**shared, **dict(overrides.get(name, {}))})
             for name, X in features.items()}

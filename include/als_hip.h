@@ -348,6 +348,15 @@ int als_graph_classify(int64_t n, int topk, const float* top_val, const int32_t*
                        const int32_t* top_cnt, uint8_t* own, uint8_t* mirror, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Item-feature normalisation (scripts/prepare_features.py:95-124, 131-201) of a float64 [n][d] matrix X (device):
+ * method 0 none (cast), 1 row_l1, 2 row_l2, 3 col_zscore, 4 col_minmax; out: float32 [n][d].  Sums run in numpy's
+ * order, so out is bitwise the reference's result.  colwork: 2*d doubles (methods 3, 4).  status (device int32,
+ * zeroed by the caller): bit 0 set when X holds a NaN / inf (the reference raises ValueError; impute first).
+ * ------------------------------------------------------------------------- */
+int als_normalize_features(int64_t n, int d, const double* X, int method, double eps, float* out,
+                           double* colwork, int32_t* status, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Host-side set-up passes (HOST pointers, synchronous, no GPU involved).  They replace the reference's
  * per-fit index-list construction (scripts/als.py:332-340) and prepare the inputs of the entry points above;
  * the named caller times fit + predict together (scripts/evaluate_models.py:245-255), so this is inside its

@@ -9,6 +9,6 @@ while [ $# -ge 2 ]; do
   tag=$1; flags=$2; shift 2
   /opt/rocm/bin/hipcc -O3 -fno-slp-vectorize -std=c++17 --offload-arch=gfx950 -fPIC -I../../include -Wno-unused-function $flags -c row_solve.hip -o row_solve_$tag.o
   /opt/rocm/bin/hipcc -O3 -fno-slp-vectorize -std=c++17 --offload-arch=gfx950 -fPIC -I../../include -Wno-unused-function $flags -c row_pair.hip -o row_pair_$tag.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libals_hip_$tag.so row_solve_$tag.o row_pair_$tag.o row_solve_f64.o gs_sweep.o graph_build.o stats.o predict.o w_step.o spd_solve.o host_setup.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libals_hip_$tag.so row_solve_$tag.o row_pair_$tag.o row_solve_f64.o gs_sweep.o graph_build.o features.o stats.o predict.o w_step.o spd_solve.o host_setup.o
   echo "built libals_hip_$tag.so ($flags)"
 done

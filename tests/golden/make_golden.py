@@ -149,6 +149,32 @@ def feature_norm_case():
     print("feature-normaliser fixture:", sorted(out)[:4], "...")
 
 
+def feature_norm_wide_case():
+    """Reference outputs on shapes that reach every branch of numpy's summation order (the device normaliser
+    reproduces it): 21 columns (interleaved partial sums + tail), 150 columns (recursive halves), a single column
+    of 5000 items (column statistics summed pairwise), 9 columns with missing entries (imputation)."""
+    from scripts.prepare_features import normalize_feature
+    rng = np.random.default_rng(302)
+    mats = {
+        "w21": rng.normal(size=(600, 21)) * 10.0 ** rng.uniform(-2, 2, size=(600, 21)),
+        "w150": rng.normal(size=(120, 150)) * 10.0 ** rng.uniform(-2, 2, size=(120, 150)),
+        "w1": rng.integers(1900, 2020, size=5000).astype(np.float64) + rng.normal(size=5000) * 1e-3,
+        "w2": rng.normal(size=(700, 2)) * 5.0 + 2.0,
+    }
+    mats["w21"][5] = 0.0                                            # zero row
+    mats["w21"][:, 7] = -3.0                                        # constant column
+    holes = rng.normal(size=(200, 9)) * 4.0
+    holes[rng.random(size=holes.shape) < 0.1] = np.nan
+    holes[3, 2], holes[8, 2], holes[:, 6] = np.inf, -np.inf, np.nan
+    out = dict(mats, holes=holes)
+    for method in ("none", "row_l1", "row_l2", "col_zscore", "col_minmax"):
+        for name, X in mats.items():
+            out[f"{name}_{method}"] = normalize_feature(X, method)
+        out[f"holes_{method}"] = normalize_feature(holes, method, impute="col_median")
+    np.savez_compressed(os.path.join(HERE, "feat_norm_wide.npz"), **out)
+    print("wide feature-normaliser fixture written")
+
+
 def main():
     only = sys.argv[1:]            # optional fixture-name prefixes: regenerate only those
     global run_case
@@ -161,6 +187,7 @@ def main():
     else:
         folds_case()
         feature_norm_case()
+        feature_norm_wide_case()
     sim10 = dict(source="feature", feature_name="genres", metric="cosine",
                  topk=10, eps=1e-8)
     # g1: plain U/V (+ the always-on mu / bias terms)

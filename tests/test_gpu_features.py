@@ -1,0 +1,69 @@
+"""SURVEY 8(f) n4 on the device: `als_normalize_features` (csrc/features.hip) against outputs of the reference's
+scripts/prepare_features.py stored in tests/golden/feat_norm_50x6.npz and feat_norm_wide.npz - bitwise, because
+the kernels sum in numpy's order (pairwise along the contiguous axis, row after row along the other)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+METHODS = ("none", "row_l1", "row_l2", "col_zscore", "col_minmax")
+
+
+def _dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected (-m gpu) but no ROCm device is visible")
+    return "cuda:0"
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_device_normaliser_is_bitwise_the_reference(method):
+    from collaborative_filtering_amd import features as F
+    dev = _dev()
+    small = np.load(os.path.join(HERE, "golden", "feat_norm_50x6.npz"))
+    wide = np.load(os.path.join(HERE, "golden", "feat_norm_wide.npz"))
+    a = F.normalize_feature_device(small["clean"], method, device=dev)
+    assert a.dtype.is_floating_point and a.element_size() == 4
+    assert np.array_equal(a.cpu().numpy(), small[f"clean_{method}"])
+    b = F.normalize_feature_device(small["X"], method, impute="col_median", device=dev)
+    assert np.array_equal(b.cpu().numpy(), small[f"imputed_{method}"], equal_nan=True)
+    for name in ("w21", "w150", "w1", "w2"):
+        got = F.normalize_feature_device(wide[name], method, device=dev).cpu().numpy()
+        want = wide[f"{name}_{method}"]
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), (name, method, float(np.abs(got - want).max()))
+    h = F.normalize_feature_device(wide["holes"], method, impute="col_median", device=dev).cpu().numpy()
+    assert np.array_equal(h, wide[f"holes_{method}"])
+
+
+def test_device_normaliser_dict_and_errors():
+    from collaborative_filtering_amd import features as F
+    dev = _dev()
+    g = np.load(os.path.join(HERE, "golden", "feat_norm_50x6.npz"))
+    d = F.normalize_features_dict({"genres": g["clean"], "years": g["years"]}, method="none", impute="col_median",
+                                  per_feature_overrides={"genres": {"method": "row_l2"},
+                                                         "years": {"method": "col_zscore"}}, device=dev)
+    assert np.array_equal(d["genres"].cpu().numpy(), g["dict_genres"])
+    assert np.array_equal(d["years"].cpu().numpy(), g["dict_years"]) and tuple(d["years"].shape) == (50, 1)
+    with pytest.raises(ValueError, match="Unknown method"):
+        F.normalize_feature_device(g["clean"], "l2", device=dev)
+    with pytest.raises(ValueError, match="Unknown impute"):
+        F.normalize_feature_device(g["clean"], "none", impute="mean", device=dev)
+    with pytest.raises(ValueError, match="NaN/Inf"):
+        F.normalize_feature_device(g["X"], "row_l2", device=dev)
+    with pytest.raises(TypeError):
+        F.normalize_feature_device(g["clean"].astype(np.float32), "row_l2", device=dev)
+
+
+def test_device_normaliser_at_catalogue_size():
+    """10^6 items x 20 columns (the BASELINE configs[4] item count): equal to the host form (numpy) bit for bit."""
+    from collaborative_filtering_amd import features as F
+    dev = _dev()
+    rng = np.random.default_rng(9)
+    X = (rng.random(size=(1_000_000, 20)) < 0.15).astype(np.float64) + rng.normal(size=(1_000_000, 20)) * 1e-3
+    for method in ("row_l2", "col_zscore"):
+        got = F.normalize_feature_device(X, method, device=dev).cpu().numpy()
+        assert np.array_equal(got, F.normalize_feature(X, method))
