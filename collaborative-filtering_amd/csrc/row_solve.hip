@@ -152,6 +152,105 @@ __device__ __forceinline__ void process_chunk_bf16x3(RowAcc<KB>& A, int off_l, f
     }
 }
 
+// F^T r and F^T 1 on the matrix cores as well (ALS_RHS_MFMA): one more MFMA chain per column block whose row
+// operand is "r" in rows 0..7 and "1" in rows 8..15 - lane (c, q) supplies row c, so lanes c < 8 hand in the split
+// residuals of ratings 8q .. 8q+7 and lanes c >= 8 the constant 1 (bf16 1.0 in the high plane, zeros in the other
+// two).  Output block b: rows 0..7 (lanes q < 2) all hold (F^T r)[16b + c], rows 8..15 (q >= 2) hold (F^T 1)[16b + c];
+// the same six-product scheme as the Gram, so F^T 1 is the exact fp32-accumulated sum h + m + l.  This takes the
+// 2 VALU operations per gathered element of the FMA form off the VALU (64 of ~300 instructions of a group at k = 64).
+// MEASURED AND NOT ADOPTED (profiles/r02_ab_rhs_mfma.txt, cfg 4): U-step 7.9 instead of 6.5 ms, V-step 5.7 instead of
+// 4.45 ms - 84 instead of 60 matrix instructions per group and 29 spilled registers at the 168-register cap cost
+// more than the 64 vector instructions save; results agree (train RMSE 0.419939242 vs 0.419939198).  Kept behind
+// the switch because the pre-split-planes idea would need it.
+// rp*: the residual of rating t, split exactly into three bf16 terms and packed with its neighbour's by lane t
+// (even t: {r[t+1] : r[t]}; odd t: the constant row) - formed once per 64-rating chunk, fetched with ds_bpermute.
+#ifndef ALS_RHS_MFMA
+#define ALS_RHS_MFMA 0
+#endif
+
+__device__ __forceinline__ void pack_residual_planes(float r_l, int lane, int& rph, int& rpm, int& rpl) {
+    auto nb = [](int x) {       // the value of lane t ^ 1
+        return __builtin_amdgcn_update_dpp(0, x, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
+    };
+    const int h = __float_as_int(r_l) & 0xFFFF0000;
+    const float r1 = r_l - __int_as_float(h);                   // exact
+    const int m = __float_as_int(r1) & 0xFFFF0000;
+    const int l = __float_as_int(r1 - __int_as_float(m));      // exact, <= 8 significant bits
+    // (the cross-lane reads happen in ALL lanes, before the select: inside a conditional the odd lanes would be
+    // masked off and the even ones would read zeros from them)
+    const int ph = __builtin_amdgcn_perm(nb(h), h, 0x07060302);
+    const int pm = __builtin_amdgcn_perm(nb(m), m, 0x07060302);
+    const int pl = __builtin_amdgcn_perm(nb(l), l, 0x07060302);
+    const bool odd = lane & 1;
+    rph = odd ? 0x3F803F80 : ph;
+    rpm = odd ? 0 : pm;
+    rpl = odd ? 0 : pl;
+}
+
+template <int KB, bool FULL>
+__device__ __forceinline__ void process_chunk_bf16x3_rm(RowAcc<KB>& A, f32x4 (&racc)[KB], int off_l, int rph, int rpm,
+                                                        int rpl, int nvalid, const float* __restrict__ Fc, int q,
+                                                        int c) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (!FULL && 32 * g >= nvalid) break;
+        int off_t[8];
+        float f[8][KB];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) off_t[j] = bperm_i(off_l, 32 * g + 8 * q + j);
+        i32x4 RH, RM, RL;
+        const int rsel = 32 * g + 8 * q + (c >= 8 ? 1 : 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            RH[e] = bperm_i(rph, rsel + 2 * e);
+            RM[e] = bperm_i(rpm, rsel + 2 * e);
+            RL[e] = bperm_i(rpl, rsel + 2 * e);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) load_frow<KB>(Fc + (uint32_t)off_t[j], f[j]);
+        i32x4 H[KB], M[KB], L[KB];
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                int hw, mw, lw;
+                split3(f[j][b], f[j + 1][b], hw, mw, lw);
+                H[b][j >> 1] = hw; M[b][j >> 1] = mw; L[b][j >> 1] = lw;
+            }
+        }
+        const bf16x8 rh = __builtin_bit_cast(bf16x8, RH), rm = __builtin_bit_cast(bf16x8, RM),
+                     rl = __builtin_bit_cast(bf16x8, RL);
+#pragma unroll
+        for (int bi = 0; bi < KB; ++bi) {
+            const bf16x8 hi = __builtin_bit_cast(bf16x8, H[bi]), mi = __builtin_bit_cast(bf16x8, M[bi]),
+                         li = __builtin_bit_cast(bf16x8, L[bi]);
+            {
+                f32x4 acc = racc[bi];                    // smallest terms first, as the Gram blocks
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl, hi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh, li, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rm, mi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rm, hi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh, mi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh, hi, acc, 0, 0, 0);
+                racc[bi] = acc;
+            }
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) {
+                f32x4 acc = A.acc[blk_idx(bi, bj)];
+                const bf16x8 hj = __builtin_bit_cast(bf16x8, H[bj]), mj = __builtin_bit_cast(bf16x8, M[bj]),
+                             lj = __builtin_bit_cast(bf16x8, L[bj]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(li, hj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, lj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mi, mj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mi, hj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, mj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, hj, acc, 0, 0, 0);
+                A.acc[blk_idx(bi, bj)] = acc;
+            }
+        }
+    }
+}
+
 // The same Gram in groups of 16 ratings on v_mfma_f32_16x16x16_bf16 (4 k-elements per lane): lane (c,q) takes
 // ratings 4q .. 4q+3 of a 16-rating group.  Half the operand and staging registers of the 32-rating form
 // (H / M / L: 24 instead of 48, gathered rows: 4 x KB instead of 8 x KB), twice the MFMA instructions.
@@ -247,6 +346,12 @@ __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __
     const int c = lane & 15, q = lane >> 4;
     const float* Fc = F + KB * c;
     int nflush = 0;
+#if ALS_RHS_MFMA && !ALS_GRAM_G16
+    f32x4 racc[KB];
+    float rtot[KB];
+#pragma unroll
+    for (int b = 0; b < KB; ++b) { racc[b] = f32x4{0.f, 0.f, 0.f, 0.f}; rtot[b] = 0.f; }
+#endif
     // software pipeline over 64-rating chunks: indices two chunks ahead,
     // value + opposite-side bias one chunk ahead of the factor-row gathers
     // indices / values are read once: non-temporal, so that they do not push the gathered factor rows (244 MiB of
@@ -278,6 +383,11 @@ __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __
 #if ALS_GRAM_G16
             if (nvalid == 64) process_chunk_bf16x3_g16<KB, true>(A, off0, r0, 64, Fc, q);
             else              process_chunk_bf16x3_g16<KB, false>(A, off0, r0, nvalid, Fc, q);
+#elif ALS_RHS_MFMA
+            int rph, rpm, rpl;
+            pack_residual_planes(r0, lane, rph, rpm, rpl);
+            if (nvalid == 64) process_chunk_bf16x3_rm<KB, true>(A, racc, off0, rph, rpm, rpl, 64, Fc, q, c);
+            else              process_chunk_bf16x3_rm<KB, false>(A, racc, off0, rph, rpm, rpl, nvalid, Fc, q, c);
 #else
             if (nvalid == 64) process_chunk_bf16x3<KB, true>(A, off0, r0, 64, Fc, q);
             else              process_chunk_bf16x3<KB, false>(A, off0, r0, nvalid, Fc, q);
@@ -285,6 +395,10 @@ __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __
             if (((base >> 6) + 1) % (FLUSH_GROUPS / 2) == 0 && base + 64 < len) {
                 flush_acc<KB>(A, Ls, lane, nflush == 0);
                 ++nflush;
+#if ALS_RHS_MFMA && !ALS_GRAM_G16
+#pragma unroll
+                for (int b = 0; b < KB; ++b) { rtot[b] += racc[b][0]; racc[b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#endif
             }
         }
     }
@@ -292,6 +406,20 @@ __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __
         unflush_acc<KB>(A, Ls, lane);
         wave_lds_sync();
     }
+#if ALS_RHS_MFMA && !ALS_GRAM_G16
+    if (MODE != 0) {
+        // every register of racc[b] holds (F^T r)[16b + c] in the lanes q < 2 and (F^T 1)[16b + c] in the lanes
+        // q >= 2; the row's tail sums the four q groups of A.rhs / A.cs (per-lane partials of the FMA form, also the
+        // format of the split-row slots), so the totals go to the q = 0 lanes and zeros to the others
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+            const float tot = rtot[b] + racc[b][0];
+            const float fr = bperm_f(tot, c), f1 = bperm_f(tot, 32 + c);
+            A.rhs[b] = (q == 0) ? fr : 0.f;
+            A.cs[b] = (q == 0) ? f1 : 0.f;
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
