@@ -81,6 +81,8 @@ def main():
     run(k, 16384, 100, 160, False, be, dev, "U-like")
     run(k, 16384, 500, 700, True, be, dev, "V-like")
     run(k, 16384, 100, 160, True, be, dev, "V-like short")
+    run(k, 8192, 900, 1100, True, be, dev, "V-like long")
+    run(k, 8192, 900, 1100, False, be, dev, "U-like long")
 
 
 if __name__ == "__main__":
