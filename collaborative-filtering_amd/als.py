@@ -217,6 +217,14 @@ class SweepNotResident(RuntimeError):
     per-level launches, which have no residency requirement."""
 
 
+def _host_features(features):
+    """The features dict with device tensors (e.g. the output of features.normalize_feature_device) brought to the
+    host: the fit keeps float32 / float64 copies of its own in HBM and validates on the host, as the reference."""
+    if not features:
+        return {}
+    return {name: (X.detach().cpu().numpy() if torch.is_tensor(X) else X) for name, X in features.items()}
+
+
 class ALS:
     """Alternating least squares with biases, feature projections and a graph
     Laplacian:  R ~ U (V + sum_f X_f W_f)^T + mu + b_u + b_i."""
@@ -314,7 +322,7 @@ class ALS:
     def _fit_sides(self, csr, csc, features, tol, min_iters, verbose, S, run: bool = True,
                    S_trusted: bool = False) -> "ALS":
         m, n = csr.nrows, csc.nrows
-        features = features or {}
+        features = _host_features(features)
         for name, X in features.items():                     # scripts/als.py:346-351
             if X.shape[0] != n:
                 raise ValueError(f"Feature '{name}' has {X.shape[0]} rows; "
@@ -380,6 +388,7 @@ class ALS:
 
     # -------------------------------------------------------------- predict
     def _check_predict(self, features):
+        features = _host_features(features)
         if self.U is None or self.V is None:                 # scripts/als.py:554-555
             raise RuntimeError("Model must be fitted before prediction.")
         n = self.V.shape[0]

@@ -67,3 +67,24 @@ def test_device_normaliser_at_catalogue_size():
     for method in ("row_l2", "col_zscore"):
         got = F.normalize_feature_device(X, method, device=dev).cpu().numpy()
         assert np.array_equal(got, F.normalize_feature(X, method))
+
+
+def test_fit_takes_device_normalised_features():
+    """The normaliser's device tensors go straight into ALS.fit: same fit as with the host-normalised arrays
+    (fixture g4: genres + years projections), bit for bit."""
+    from collaborative_filtering_amd import features as F
+    from tests.common import Golden
+    from tests.test_gpu_parity import _model_for
+    dev = _dev()
+    g = Golden("g4_feat_uw2")
+    raw = {name: np.asarray(X, dtype=np.float64) for name, X in g.features.items()}
+    over = {"genres": {"method": "row_l2"}, "years": {"method": "col_zscore"}}
+    host = F.normalize_features_dict(raw, per_feature_overrides=over)
+    devf = F.normalize_features_dict(raw, per_feature_overrides=over, device=dev)
+    assert all(np.array_equal(devf[n].cpu().numpy(), host[n]) for n in raw)
+    r, c, v = g.train
+    a = _model_for(g).fit_coo(r, c, v, (g.m, g.n), features=host, tol=None, verbose=0)
+    b = _model_for(g).fit_coo(r, c, v, (g.m, g.n), features=devf, tol=None, verbose=0)
+    assert np.array_equal(a.U, b.U) and np.array_equal(a.V, b.V)
+    assert all(np.array_equal(a.W[n], b.W[n]) for n in a.W)
+    assert np.array_equal(a.predict_at(g.val_flat(), host), b.predict_at(g.val_flat(), devf))
