@@ -102,12 +102,76 @@ __device__ __forceinline__ void process_chunk(RowAcc<KB>& A, int off_l, float r_
 // group: the 8 values it loads per block are exactly its 8 k-elements of the A/B operand.
 // ---------------------------------------------------------------------------
 
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+// Last group of a row with at most 16 ratings left (ALS_TAIL16): the same six products on
+// v_mfma_f32_16x16x16_bf16 - lane (c, q) takes ratings t0 + 4q .. 4q+3 - instead of a 32-rating group that is
+// more than half padding.  (As the only group size this form measured slower, profiles/r02_ab_g16.txt: twice the
+// MFMA instructions per rating; as the tail it replaces a whole group by half of one.)
+// MEASURED AND NOT ADOPTED (profiles/r02_ab_tail16.txt, cfg 4): U-step 6.90 vs 6.88 ... 6.98 ms, V-step 4.63 vs
+// 4.47 ms - the second code path costs 12 spilled registers at the 168-register cap and what it saves (a quarter
+// of a group per row on average) does not show.
+#ifndef ALS_TAIL16
+#define ALS_TAIL16 0
+#endif
+template <int KB>
+__device__ __forceinline__ void process_tail16_bf16x3(RowAcc<KB>& A, int off_l, float r_l, int t0,
+                                                      const float* __restrict__ Fc, int q) {
+    int off_t[4];
+    float r_t[4];
+    float f[4][KB];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        off_t[j] = bperm_i(off_l, t0 + 4 * q + j);
+        r_t[j] = bperm_f(r_l, t0 + 4 * q + j);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) load_frow<KB>(Fc + (uint32_t)off_t[j], f[j]);
+    i32x2 H[KB], M[KB], L[KB];
+#pragma unroll
+    for (int b = 0; b < KB; ++b) {
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+            const float x0 = f[j][b], x1 = f[j + 1][b];
+            A.rhs[b] = fmaf(x0, r_t[j], A.rhs[b]);
+            A.rhs[b] = fmaf(x1, r_t[j + 1], A.rhs[b]);
+            A.cs[b] += x0 + x1;
+            int hw, mw, lw;
+            split3(x0, x1, hw, mw, lw);
+            H[b][j >> 1] = hw; M[b][j >> 1] = mw; L[b][j >> 1] = lw;
+        }
+    }
+#pragma unroll
+    for (int bi = 0; bi < KB; ++bi)
+#pragma unroll
+        for (int bj = 0; bj <= bi; ++bj) {
+            f32x4 acc = A.acc[blk_idx(bi, bj)];
+            const bf16x4 hi = __builtin_bit_cast(bf16x4, H[bi]), hj = __builtin_bit_cast(bf16x4, H[bj]);
+            const bf16x4 mi = __builtin_bit_cast(bf16x4, M[bi]), mj = __builtin_bit_cast(bf16x4, M[bj]);
+            const bf16x4 li = __builtin_bit_cast(bf16x4, L[bi]), lj = __builtin_bit_cast(bf16x4, L[bj]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(li, hj, acc, 0, 0, 0);     // smallest terms first
+            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi, lj, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(mi, mj, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(mi, hj, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi, mj, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi, hj, acc, 0, 0, 0);
+            A.acc[blk_idx(bi, bj)] = acc;
+        }
+}
+
 template <int KB, bool FULL>
 __device__ __forceinline__ void process_chunk_bf16x3(RowAcc<KB>& A, int off_l, float r_l, int nvalid,
                                                      const float* __restrict__ Fc, int q) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         if (!FULL && 32 * g >= nvalid) break;
+#if ALS_TAIL16
+        if (!FULL && nvalid - 32 * g <= 16) {
+            process_tail16_bf16x3<KB>(A, off_l, r_l, 32 * g, Fc, q);
+            break;
+        }
+#endif
         int off_t[8];
         float r_t[8];
         float f[8][KB];
@@ -257,8 +321,6 @@ __device__ __forceinline__ void process_chunk_bf16x3_rm(RowAcc<KB>& A, f32x4 (&r
 #ifndef ALS_GRAM_G16
 #define ALS_GRAM_G16 0
 #endif
-typedef short bf16x4 __attribute__((ext_vector_type(4)));
-typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 template <int KB, bool FULL>
 __device__ __forceinline__ void process_chunk_bf16x3_g16(RowAcc<KB>& A, int off_l, float r_l, int nvalid,
