@@ -676,7 +676,7 @@ class _Engine:
         self.hist = torch.zeros(max(model.n_iters, 1), 6, dtype=f64, device=device)
         self._graphs = {}
         self.graphs_captured = 0
-        self.replay_ok = True           # run() clears it for fits with early stopping (see there)
+        self.replay_ok = True           # (diagnostics: set False to force eager iterations)
         self.iters_run = 0
 
     # ------------------------------------------------------------- helpers
@@ -1018,18 +1018,14 @@ class _Engine:
         n_iters = int(md.n_iters)
         rm = md.history["train_rmse"]
         base_len = len(rm)
-        # Captured-graph replay (hip_graph=True) is used for fits WITHOUT early stopping only.  With `tol` the host
-        # reads the status words and the RMSE history back after every iteration; on this ROCm runtime (7.2) those
-        # device-to-host copies between launches of an instantiated graph corrupt later replays - the iteration
-        # after a few dozen interleaved copies computes garbage (reproduced by profiles/debug_sweep_hip_graph.py:
-        # bitwise equal to the eager fit with tol=None, garbage from iteration 21 / 24 with 3 / 1 `.item()` reads per
-        # iteration in between).  Such fits run eagerly.
-        # (round 2, profiles/graph_early_stop_stress.py: with the read-backs packed into ONE contiguous 128-byte copy
-        # per iteration most fits replay bitwise equal to the eager run over 120 iterations, but fits with both the
-        # Laplacian sweep and the W-step still diverge after ~40 iterations - and at the reference's scale replay is
-        # no faster than eager launches, 100 vs 119 ms per 120 iterations at best.  ALS_GRAPH_EARLY_STOP=1 forces
-        # replay for such fits: diagnostics only.)
-        self.replay_ok = tol is None or os.environ.get("ALS_GRAPH_EARLY_STOP", "0") == "1"
+        # Captured-graph replay (hip_graph=True) also serves fits with early stopping: the host reads ONE contiguous
+        # 128-byte block per iteration between the replays.  (Round 1 / early round 2 had replay limited to tol=None
+        # because "host read-backs corrupt later replays"; the real cause was the sweep's hipMemsetD32Async: with the
+        # two iteration graphs alive - W-step / no-W-step variant - each holding a memset node, replays went wrong
+        # from the first switch back, reads or no reads.  The reset is a kernel now (gs_sweep.hip) and replay is
+        # bitwise the eager fit over 120 iterations with per-iteration reads: profiles/graph_early_stop_stress.py,
+        # tests/test_gpu_parity.py::test_hip_graph_replay_with_early_stopping_reads.)
+        self.replay_ok = True
         if self.feat_names:
             self.be.compose_z(self.V, self.Xcat, self.Wcat, self.Z)              # :411
         seen = list(rm)                 # train RMSE so far (earlier fits of the same model + this one)

@@ -546,6 +546,17 @@ int launch_gs(const als_gs_sweep_params* p, hipStream_t st) {
 
 }  // namespace
 
+namespace {
+// publish[0 .. nwords) = word (nwords is a multiple of 16: rows x padded k); 16 bytes per thread and step
+__global__ __launch_bounds__(256)
+void k_fill_words(uint32_t* __restrict__ dst, int64_t nwords, uint32_t word) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = {word, word, word, word};
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nwords / 4; e += (int64_t)gridDim.x * 256)
+        reinterpret_cast<u32x4*>(dst)[e] = v;
+}
+}  // namespace
+
 extern "C" int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t* S_idx_wait, float* publish,
                                      int64_t nrows, float* nondep, int32_t* err, void* stream) {
     if (!p || !S_idx_wait || !publish || !err || nrows < 0) return ALS_E_BADARG;
@@ -556,9 +567,15 @@ extern "C" int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t
         return ALS_E_BADARG;
     if (p->stat_out && (!p->sumr2 || !p->lambda_eff)) return ALS_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    if (p->nitems > 0 && nrows > 0 &&
-        hipMemsetD32Async((hipDeviceptr_t)publish, (int)GS_SENTINEL, (size_t)nrows * ld, st) != hipSuccess)
-        return ALS_E_LAUNCH;
+    // (a fill kernel, not hipMemsetD32Async: with TWO captured iteration graphs alive - W-step / no-W-step variant -
+    // that each hold a memset node, replays went wrong from the first switch back on ROCm 7.2; with the reset as a
+    // kernel node they are bitwise the eager fit, profiles/graph_early_stop_stress.py)
+    if (p->nitems > 0 && nrows > 0) {
+        const int64_t nwords = nrows * ld;
+        const unsigned grid = (unsigned)((nwords / 4 + 255) / 256 < 8192 ? (nwords / 4 + 255) / 256 : 8192);
+        hipLaunchKernelGGL(k_fill_words, dim3(grid > 0 ? grid : 1), dim3(256), 0, st, (uint32_t*)publish, nwords,
+                           (uint32_t)GS_SENTINEL);
+    }
     switch (ld / 16) {
         case 1: return launch_gs_dataflow<1>(p, S_idx_wait, publish, err, p->nitems, st, nondep);
         case 2: return launch_gs_dataflow<2>(p, S_idx_wait, publish, err, p->nitems, st, nondep);

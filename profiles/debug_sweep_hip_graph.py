@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Reproducer kept for the record: replaying the captured iteration graphs while the host reads
-the engine's status words / history back between the launches - what early stopping needs - goes wrong on this
-image (ROCm 7.2, torch 2.10): from some iteration on the replays compute garbage.  The engine therefore replays
-graphs only for fits without early stopping.  One reference-scale fit (610 x 4980, k = 16, features + Laplacian),
-30 iterations, eager against replay with different host reads after every iteration >= 9."""
+"""Kept for the record: replaying the captured iteration graphs while the host reads the engine's
+status words / history back between the launches.  Until the sweep's hipMemsetD32Async was replaced by a fill kernel
+this went wrong from iteration 21 on (the cause was the memset node in two live graphs, not the reads); now every
+mode prints a zero difference.  One reference-scale fit (610 x 4980, k = 16, features + Laplacian), 30 iterations,
+eager against replay with different host reads after every iteration >= 9."""
 import os
 import sys
 
@@ -45,7 +45,9 @@ def fit(hip, mode):
             if "row" in mode:
                 eng.hist_row.cpu().numpy()               # contiguous 6 doubles: a D2H copy only
     torch.cuda.synchronize()
-    return eng.hist[:30, 0].cpu().numpy()
+    h = eng.hist[:30, 0].cpu().numpy()
+    eng._graphs.clear()          # as _Engine.run does: no captured graph may die during another engine's capture
+    return h
 
 
 e = fit(False, "")

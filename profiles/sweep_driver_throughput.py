@@ -34,7 +34,7 @@ for t in range(12):                      # a dozen "trials" the way the tuner's 
 item_bin, _ = cv.popularity_bins(np.bincount(ratings.cols, minlength=n), 5)
 
 out = {}
-for hip_graph in (False,):      # fits with early stopping run eagerly (als._Engine.run)
+for hip_graph in (False, True):  # eager launches / captured-graph replay (early stopping reads between replays)
     kw = {"hip_graph": hip_graph}
     # warm both paths (library load, graph memoisation of the per-fit path)
     cv.eval_variant_cv("w", ratings, feats, folds, dict(params[0]), item_bin, 5, cv.ES_TOL, cv.ES_MIN_ITERS, {}, als_kwargs=kw)

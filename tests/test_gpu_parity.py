@@ -382,8 +382,7 @@ def test_hip_graph_replay_is_bitwise_the_eager_fit(name):
     kw = dict(features=g.features or None, tol=g.cfg["tol"], min_iters=g.cfg["min_iters"], verbose=0)
     a = _model_for(g).fit_coo(r, c, v, (g.m, g.n), **kw)
     b = _model_for(g, hip_graph=True).fit_coo(r, c, v, (g.m, g.n), **kw)
-    # fits with early stopping run eagerly (host read-backs between replays are not safe on this runtime)
-    assert (b._eng.graphs_captured > 0) == (g.cfg["tol"] is None)
+    assert b._eng.graphs_captured > 0                        # also with early stopping (g6: stops at iteration 32)
     assert len(a.history["train_rmse"]) == len(b.history["train_rmse"])
     for key in ("U", "V", "b_u", "b_i"):
         np.testing.assert_array_equal(getattr(a, key), getattr(b, key), err_msg=key)
@@ -414,7 +413,7 @@ def test_nondep_prepass_is_bitwise_the_in_sweep_gather(name, k, monkeypatch):
 
 def test_hip_graph_replay_over_many_iterations():
     """30 iterations with features (W-step every 5th) and the Laplacian: the W-step / no-W-step graphs are replayed
-    alternately many times, with no host read-back in between (tol=None).  Bitwise the eager fit."""
+    alternately many times (tol=None: no host read-back in between).  Bitwise the eager fit."""
     _cuda()
     from collaborative_filtering_amd import ALS, ALSConfig, BiasesConfig, CoreConfig, GraphConfig, GraphSimConfig
     g = Golden("g5_graph_a0.5")
@@ -431,6 +430,37 @@ def test_hip_graph_replay_over_many_iterations():
     np.testing.assert_array_equal(a.V, b.V)
     for f in lw:
         np.testing.assert_array_equal(a.W[f], b.W[f])
+
+
+def test_hip_graph_replay_with_early_stopping_reads():
+    """Reference-scale shape (610 x 4980, 100K ratings), Laplacian + features (W-step every 5th iteration, so the two
+    captured graphs alternate): replay with the per-iteration read-back of early stopping is bitwise the eager fit -
+    70 iterations with a tolerance that never triggers, and a fit that does stop early (same stopping iteration).
+    Regression test for the memset-node issue (gs_sweep.hip: the publication buffer is reset by a kernel)."""
+    _cuda()
+    from collaborative_filtering_amd import ALS, ALSConfig, BiasesConfig, CoreConfig, GraphConfig, GraphSimConfig
+    from tests.synth import make_features, make_ratings
+    m, n = 610, 4980
+    r, c, v = make_ratings(m, n, 100000, 5)
+    G, Y = make_features(n, 6)
+    feats = {"genres": G, "years": Y}
+    lw = {"genres": 31.1, "years": 28.3}
+    for n_iters, tol, min_iters in ((70, -1.0, 5), (100, 1e-4, 10)):
+        cfg = ALSConfig(core=CoreConfig(n_factors=16, n_iters=n_iters, lambda_u=8.74, lambda_v=7.02,
+                                        pop_reg_mode="inverse_sqrt", update_w_every=5),
+                        biases=BiasesConfig(3.0, 2.0),
+                        graph=GraphConfig(alpha=0.83, sim=GraphSimConfig(feature_name="genres", topk=50, eps=1e-8)))
+        a = ALS(cfg, lambda_w=lw).fit_coo(r, c, v, (m, n), features=feats, tol=tol, min_iters=min_iters, verbose=0)
+        b = ALS(cfg, lambda_w=lw, hip_graph=True).fit_coo(r, c, v, (m, n), features=feats, tol=tol,
+                                                           min_iters=min_iters, verbose=0)
+        assert b._eng.graphs_captured == 2
+        assert len(a.history["train_rmse"]) == len(b.history["train_rmse"])
+        assert (len(a.history["train_rmse"]) == n_iters) == (tol < 0)
+        np.testing.assert_array_equal(a.history["train_rmse"], b.history["train_rmse"])
+        np.testing.assert_array_equal(a.U, b.U)
+        np.testing.assert_array_equal(a.V, b.V)
+        for f in lw:
+            np.testing.assert_array_equal(a.W[f], b.W[f])
 
 
 def test_streamed_sweep_form_equals_the_image_form(tmp_path):
