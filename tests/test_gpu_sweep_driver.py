@@ -102,9 +102,9 @@ def test_trial_protocol_reporting_and_pruning():
 
 
 def test_driver_with_captured_iterations_is_bitwise_the_eager_driver():
-    """hip_graph=True inside the driver.  Fits with early stopping run eagerly whatever the flag says (host
-    read-backs between replays are not safe on this runtime, als._Engine.run); fits without it replay captured
-    iterations while the set-up products come from the shared cache.  Identical scores either way."""
+    """hip_graph=True inside the driver: fits with and without early stopping replay captured iterations (one
+    contiguous read-back per iteration in between) while the set-up products come from the shared cache.
+    Identical scores either way."""
     g, ratings, folds = _setup()
     for kw in ({}, {"es_tol": None}):
         a = sweep.SweepDriver(ratings, g.features, folds).run([dict(p) for p in PARAMS], **kw)
