@@ -10,7 +10,8 @@
 // from the V-step by-products: rhs_i - (b_i_new - b_i_old) colsum_i.  Everything is kept in perm space
 // (als_device.hpp); accumulation is fp64.
 //
-//   k_w_item_vectors   one wave per item: h_{f,i} for every feature (perm space, fp32)
+//   k_w_item_vectors   one wave per item: h_{f,i} for every feature (perm space, fp32); G_i z and all G_i xw_f as one
+//                      product on the f32 matrix cores (gsym_matmul16)
 //   k_w_accumulate     one workgroup per (feature-column pair a <= a', item chunk): partial lower blocks of
 //                      sum_i x_ia x_ia' G_i and (a == a') partial b rows; contributing items compacted per tile
 //   k_w_reduce         fixed-order sum over the chunks, written into the compact (d*k)^2 system (storage order)
@@ -26,65 +27,55 @@ __device__ __forceinline__ float gsym(const float* __restrict__ G, int ld, int r
     return (r >= c) ? G[r * ld + c] : G[c * ld + r];
 }
 
-// y = G v, v and y one value per lane (perm position p = lane + 64 rr): lane p accumulates
-// sum_j Gsym[j][p] v_j with v_j broadcast by v_readlane
+// Y = Gsym X for up to 16 vectors at once on the f32 matrix cores, straight from the lower blocks in global
+// memory - no LDS image of the Gram (66 KB at k = 128: two items per CU), so the kernels that use it run at the
+// occupancy their registers allow.  xs: LDS, [16][KP] floats, vector v in row v (unused rows zero); ys: LDS,
+// [16][KP], receives Y.  Per lower block (I, K): one b128 load in row layout (lane (c, q): G[16I + c][16K + 4q ..
+// 4q+3], the A operand of Y_I += G_IK X_K, contraction index 4q + e in step e) and four dword loads in column
+// layout (G[16I + 4q + e][16K + c], the A operand of Y_K += G_IK^T X_I); a diagonal block takes its lower triangle
+// from either layout (the two halves come from different accumulation orders: Gsym(r, c) = G[max][min], as gsym).
+// 8 (4 on the diagonal) v_mfma_f32_16x16x4_f32 per block: 256 per item at k = 128.
 template <int KB>
-__device__ __forceinline__ void gsym_matvec(const float* __restrict__ G, const int (&p)[KCfg<KB>::NR],
-                                            const float (&v)[KCfg<KB>::NR], float (&y)[KCfg<KB>::NR]) {
-    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR;
+__device__ __forceinline__ void gsym_matmul16(const float* __restrict__ G, const float* __restrict__ xs,
+                                              float* __restrict__ ys, int lane) {
+    constexpr int KP = KCfg<KB>::KP;
+    const int c = lane & 15, q = lane >> 4;
+    f32x4 xb[KB], y[KB];
 #pragma unroll
-    for (int rr = 0; rr < NR; ++rr) y[rr] = 0.f;
-#pragma unroll 4
-    for (int j = 0; j < KP; ++j) {
-        const float vj = readlane_f(v[j >> 6], j & 63);
-#pragma unroll
-        for (int rr = 0; rr < NR; ++rr) y[rr] = fmaf(gsym(G, KP, j, p[rr]), vj, y[rr]);
+    for (int K = 0; K < KB; ++K) {
+        xb[K] = *reinterpret_cast<const f32x4*>(xs + c * KP + 16 * K + 4 * q);      // X[16K + 4q + e][vector c]
+        y[K] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-}
-
-// same product from the full symmetric LDS image S (row stride KP + 1): conflict-free row reads
-template <int KB>
-__device__ __forceinline__ void lds_matvec(const float* S, const int (&p)[KCfg<KB>::NR],
-                                           const float (&v)[KCfg<KB>::NR], float (&y)[KCfg<KB>::NR]) {
-    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR;
 #pragma unroll
-    for (int rr = 0; rr < NR; ++rr) y[rr] = 0.f;
-#pragma unroll 8
-    for (int j = 0; j < KP; ++j) {
-        const float vj = readlane_f(v[j >> 6], j & 63);
+    for (int I = 0; I < KB; ++I) {
+        // all loads of block row I first (5 (I + 1) in flight), then its MFMAs
+        f32x4 ga[KB], gc[KB];
 #pragma unroll
-        for (int rr = 0; rr < NR; ++rr) y[rr] = fmaf(S[j * (KP + 1) + p[rr]], vj, y[rr]);
-    }
-}
-
-// An item's Gram is staged once as a full symmetric LDS image (coalesced row loads of the
-// lower blocks, mirrored on the way in; diagonal blocks from their lower triangle, as gsym does); matrix-
-// vector products then read LDS rows instead of half-transposed global memory.
-template <int KB>
-constexpr bool gram_fits_lds() { return KCfg<KB>::KP * (KCfg<KB>::KP + 1) * 4 <= 160 * 1024; }
-
-template <int KB>
-__device__ __forceinline__ void stage_gram_lds(const float* __restrict__ G, float* __restrict__ S, int lane) {
-    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR;
-    float gv[NR][16];
-    for (int r0 = 0; r0 < KP; r0 += 16) {
+        for (int K = 0; K <= I; ++K) {
+            const float* B = G + (16 * I) * KP + 16 * K;
+            ga[K] = *reinterpret_cast<const f32x4*>(B + c * KP + 4 * q);
 #pragma unroll
-        for (int rr = 0; rr < NR; ++rr)
+            for (int e = 0; e < 4; ++e) gc[K][e] = B[(4 * q + e) * KP + c];
+        }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                // unconditional (address clamped into the row): 16 NR independent loads in flight; what lies
-                // outside the lower blocks is dropped below
-                gv[rr][u] = G[(r0 + u) * KP + min(lane + 64 * rr, KP - 1)];
+        for (int K = 0; K <= I; ++K) {
+            if (I == K) {
+                f32x4 a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = (4 * q + e <= c) ? ga[K][e] : gc[K][e];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[I] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], xb[I][e], y[I], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[I] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[K][e], xb[K][e], y[I], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[K] = __builtin_amdgcn_mfma_f32_16x16x4f32(gc[K][e], xb[I][e], y[K], 0, 0, 0);
             }
-#pragma unroll
-        for (int rr = 0; rr < NR; ++rr)
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int r = r0 + u, c = lane + 64 * rr;
-                const bool ok = c < 16 * (r / 16 + 1) && !(c / 16 == r / 16 && c > r);
-                if (ok) { S[r * (KP + 1) + c] = gv[rr][u]; S[c * (KP + 1) + r] = gv[rr][u]; }
-            }
+        }
     }
+    // C/D layout: lane (c, q), register r = Y[16I + 4q + r][vector c]
+#pragma unroll
+    for (int I = 0; I < KB; ++I) *reinterpret_cast<f32x4*>(ys + c * KP + 16 * I + 4 * q) = y[I];
     wave_lds_sync();
 }
 
@@ -101,36 +92,34 @@ void k_w_item_vectors(int k, int64_t i0, int64_t i1, const float* __restrict__ g
     if (i >= i1) return;
     const int lane = threadIdx.x;
     const float* G = gram + i * KP * KP;
-    constexpr bool STAGE = gram_fits_lds<KB>();
-    __shared__ float S[STAGE ? KP * (KP + 1) : 1];
-    if constexpr (STAGE) stage_gram_lds<KB>(G, S, lane);
+    // vectors z, xw_0 ... xw_{nfeat-1} (rows 0 ... nfeat of xs, the rest zero) -> G z, G xw_f in ys, all at once
+    __shared__ __attribute__((aligned(16))) float xs[16 * KP], ys[16 * KP];
     int p[NR], col[NR];
-    float z[NR], gz[NR];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
         p[rr] = min(lane + 64 * rr, KP - 1);
         col[rr] = perm_to_col<KB>(p[rr]);
+        const bool mine = lane + 64 * rr < KP;
         float s = V[i * KP + col[rr]];
         for (int a = 0; a < D; ++a) s = fmaf(X[i * D + a], W[(int64_t)a * KP + col[rr]], s);    // z = V + sum_f xw_f
-        z[rr] = s;
-    }
-    if constexpr (STAGE) lds_matvec<KB>(S, p, z, gz); else gsym_matvec<KB>(G, p, z, gz);
-    const float db = b_new[i] - b_old[i];
-    float g[NR];
-#pragma unroll
-    for (int rr = 0; rr < NR; ++rr) g[rr] = rhs[i * KP + p[rr]] - db * colsum[i * KP + p[rr]] - gz[rr];
-    for (int f = 0; f < nfeat; ++f) {
-        float xw[NR], gx[NR];
-#pragma unroll
-        for (int rr = 0; rr < NR; ++rr) {
-            float s = 0.f;
-            for (int a = feat_off[f]; a < feat_off[f + 1]; ++a) s = fmaf(X[i * D + a], W[(int64_t)a * KP + col[rr]], s);
-            xw[rr] = s;
+        if (mine) xs[p[rr]] = s;
+        for (int f = 0; f < 15; ++f) {
+            float t = 0.f;
+            if (f < nfeat)
+                for (int a = feat_off[f]; a < feat_off[f + 1]; ++a) t = fmaf(X[i * D + a], W[(int64_t)a * KP + col[rr]], t);
+            if (mine) xs[(f + 1) * KP + p[rr]] = t;
         }
-        if constexpr (STAGE) lds_matvec<KB>(S, p, xw, gx); else gsym_matvec<KB>(G, p, xw, gx);
+    }
+    wave_lds_sync();
+    gsym_matmul16<KB>(G, xs, ys, lane);
+    const float db = b_new[i] - b_old[i];
 #pragma unroll
-        for (int rr = 0; rr < NR; ++rr)
-            if (lane + 64 * rr < KP) H[((int64_t)f * nrows_h + i) * KP + p[rr]] = g[rr] + gx[rr];
+    for (int rr = 0; rr < NR; ++rr) {
+        if (lane + 64 * rr < KP) {
+            const float g = rhs[i * KP + p[rr]] - db * colsum[i * KP + p[rr]] - ys[p[rr]];
+            for (int f = 0; f < nfeat; ++f)
+                H[((int64_t)f * nrows_h + i) * KP + p[rr]] = g + ys[(f + 1) * KP + p[rr]];
+        }
     }
 }
 
@@ -151,17 +140,23 @@ void k_item_stats(int64_t i0, int64_t i1, int ld, const float* __restrict__ gram
     if (i >= i1) return;
     const int lane = threadIdx.x;
     const float* G = gram + i * KP * KP;
-    constexpr bool STAGE = gram_fits_lds<KB>();
-    __shared__ float S[STAGE ? KP * (KP + 1) : 1];
-    if constexpr (STAGE) stage_gram_lds<KB>(G, S, lane);
+    __shared__ __attribute__((aligned(16))) float xs[16 * KP], ys[16 * KP];
     int p[NR];
     float z[NR], gz[NR];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
         p[rr] = min(lane + 64 * rr, KP - 1);
         z[rr] = (lane + 64 * rr < KP) ? Z[i * ld + perm_to_col<KB>(p[rr])] : 0.f;
+        if (lane + 64 * rr < KP) {
+            xs[p[rr]] = z[rr];
+#pragma unroll
+            for (int v = 1; v < 16; ++v) xs[v * KP + p[rr]] = 0.f;
+        }
     }
-    if constexpr (STAGE) lds_matvec<KB>(S, p, z, gz); else gsym_matvec<KB>(G, p, z, gz);
+    wave_lds_sync();
+    gsym_matmul16<KB>(G, xs, ys, lane);
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) gz[rr] = ys[p[rr]];
     double zgz = 0.0, zr = 0.0, zc = 0.0;
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr)
