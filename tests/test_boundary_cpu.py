@@ -76,6 +76,9 @@ def test_error_behaviour_before_any_device_work():
     bad[1, 1] = np.nan
     with pytest.raises(ValueError, match="infinite"):
         ALS(cfg).fit(R, features={"genres": bad}, verbose=0)                                   # :350-351
+    import torch
+    with pytest.raises(ValueError, match="infinite"):                  # tensors (the device normaliser's output type)
+        ALS(cfg).fit(R, features={"genres": torch.from_numpy(bad)}, verbose=0)     # are validated like arrays
     with pytest.raises(ValueError, match="pop_reg_mode"):
         ALS(ALSConfig(core=CoreConfig(4, 2, 1.0, 1.0, pop_reg_mode="linear"))).fit(R, verbose=0)   # :259
     with pytest.raises(ValueError):
