@@ -19,7 +19,7 @@ MAX_K = 160                 # ALS_MAX_K
 EXPORTS = ("als_version", "als_padded_k", "als_perm_index", "als_partial_slot_bytes", "als_partial_slot_bytes_f64",
            "als_row_solve", "als_row_solve_scratch_bytes", "als_gs_sweep", "als_gs_sweep_levels", "als_gs_sweep_dataflow", "als_residual_stats", "als_w_normal_equations", "als_spd_solve_workspace_bytes", "als_spd_solve_f64", "als_item_stats", "als_sum_pairs", "als_sumsq_partials",
            "als_sumsq", "als_history_row", "als_compose_z", "als_predict_at", "als_predict_dense",
-           "als_topk_similarity", "als_graph_classify", "als_normalize_features",
+           "als_topk_similarity", "als_graph_classify", "als_normalize_features", "als_impute_col_median",
            "als_host_coo_to_sides", "als_host_row_tasks", "als_host_level_schedule")
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -116,6 +116,7 @@ def load():
     lib.als_topk_similarity.argtypes = [_i64, _i64, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]
     lib.als_graph_classify.argtypes = [_i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.als_normalize_features.argtypes = [_i64, C.c_int, _vp, C.c_int, C.c_double, _vp, _vp, _vp, _vp]
+    lib.als_impute_col_median.argtypes = [_i64, C.c_int, _vp, _vp, _vp]
     lib.als_host_coo_to_sides.argtypes = [_i64, _i64, _i64] + [_vp] * 9
     lib.als_host_row_tasks.argtypes = [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]
     lib.als_host_level_schedule.argtypes = [_i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]

@@ -1,6 +1,7 @@
 // Item-feature normalisation on the device: the arithmetic of the reference's
 // scripts/prepare_features.py (`_row_l1` / `_row_l2` :95-106, `_col_zscore` :109-116, `_col_minmax` :119-124,
-// `normalize_feature` :131-201) on a float64 [n][d] matrix in HBM, result float32 [n][d].
+// `normalize_feature` :131-201, `_impute_col_median_inplace` :82-92) on a float64 [n][d] matrix in HBM, result
+// float32 [n][d].
 //
 // The reference computes in numpy float64 and casts once; the kernels reproduce numpy's summation ORDER so that
 // the float32 outputs are bitwise those of the reference (tests/test_gpu_features.py, fixtures written by the
@@ -126,7 +127,92 @@ void k_feat_col_apply(int64_t total, int d, const double* __restrict__ X, const 
     out[e] = (float)v;
 }
 
+// --- median imputation (prepare_features.py:82-92): NaN / +-inf -> the median of the column's finite entries -------
+// Order statistic k of a column by an MSB-first radix select on order-preserving 64-bit keys: eight passes of
+// one byte, a 256-bin LDS histogram per pass.  One workgroup per (column, which): which = 0 selects element
+// (m - 1) / 2, which = 1 element m / 2 of the m finite entries in ascending order; numpy's median is the mean of
+// the two (the same element twice for odd m).  sel[which * d + j] = value, cnt[j] = m.
+__device__ __forceinline__ unsigned long long order_key(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_value(unsigned long long k) {
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+__global__ __launch_bounds__(256)
+void k_feat_col_select(int64_t n, int d, const double* __restrict__ X, double* __restrict__ sel,
+                       long long* __restrict__ cnt) {
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ long long s_k;
+    const int j = blockIdx.x, which = blockIdx.y, t = threadIdx.x;
+    unsigned long long prefix = 0;          // the key's bytes above the current one
+    long long k = 0;
+    for (int byte = 7; byte >= 0; --byte) {
+        hist[t] = 0;
+        __syncthreads();
+        for (int64_t i = t; i < n; i += 256) {
+            const double v = X[i * d + j];
+            if (!(fabs(v) <= 1.7976931348623157e308)) continue;                 // NaN / inf: not a candidate
+            const unsigned long long key = order_key(v);
+            if (byte == 7 || (key >> (8 * (byte + 1))) == prefix) atomicAdd(&hist[(key >> (8 * byte)) & 255], 1u);
+        }
+        __syncthreads();
+        if (t == 0) {
+            if (byte == 7) {
+                long long m = 0;
+                for (int b = 0; b < 256; ++b) m += hist[b];
+                if (which == 0) cnt[j] = m;
+                k = (m == 0) ? -1 : (which == 0 ? (m - 1) / 2 : m / 2);
+            } else {
+                k = s_k;
+            }
+            int b = 0;
+            if (k >= 0) {
+                long long acc = 0;
+                for (; b < 256; ++b) {
+                    if (acc + hist[b] > k) break;
+                    acc += hist[b];
+                }
+                k -= acc;
+            }
+            s_k = k;
+            s_prefix = (prefix << 8) | (unsigned long long)(b & 255);
+        }
+        __syncthreads();
+        prefix = s_prefix;
+        k = s_k;
+        __syncthreads();
+    }
+    if (t == 0) sel[which * d + j] = (k < 0) ? 0.0 : key_value(prefix);
+}
+
+__global__ __launch_bounds__(256)
+void k_feat_fill_median(int64_t total, int d, double* __restrict__ X, const double* __restrict__ sel,
+                        const long long* __restrict__ cnt) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const double v = X[e];
+    if (fabs(v) <= 1.7976931348623157e308) return;
+    const int j = (int)(e % d);
+    // mean of the two middle elements as numpy forms it: (a + b) / 2; an all-missing column gets 0
+    X[e] = cnt[j] > 0 ? __ddiv_rn(__dadd_rn(sel[j], sel[d + j]), 2.0) : 0.0;
+}
+
 }  // namespace
+
+extern "C" int als_impute_col_median(int64_t n, int d, double* X, double* work, void* stream) {
+    if (n < 1 || d < 1 || !X || !work) return ALS_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    double* sel = work;                                     // [2][d]
+    long long* cnt = reinterpret_cast<long long*>(work + 2 * d);    // [d]
+    hipLaunchKernelGGL(k_feat_col_select, dim3((unsigned)d, 2), dim3(256), 0, st, n, d, X, sel, cnt);
+    const int64_t total = n * d;
+    hipLaunchKernelGGL(k_feat_fill_median, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, d, X, sel, cnt);
+    return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
+}
 
 extern "C" int als_normalize_features(int64_t n, int d, const double* X, int method, double eps, float* out,
                                       double* colwork, int32_t* status, void* stream) {

@@ -84,23 +84,6 @@ def normalize_feature(X: np.ndarray, method: str = "none", *, impute: str = "non
 _METHOD_CODES = {"none": 0, "row_l1": 1, "row_l2": 2, "col_zscore": 3, "col_minmax": 4}
 
 
-def _fill_with_col_median_device(X):
-    """Device form of `_fill_with_col_median`: the median of a column's finite entries is the middle of its
-    sorted finite entries (mean of the two middle ones for an even count, as numpy's), 0 for an empty column."""
-    import torch
-    bad = ~torch.isfinite(X)
-    if not bool(bad.any()):
-        return X
-    n = X.shape[0]
-    srt = torch.sort(torch.where(bad, torch.full_like(X, float("nan")), X), dim=0).values    # NaN sorts last
-    cnt = n - bad.sum(dim=0)
-    lo = torch.clamp((cnt - 1) // 2, min=0)
-    hi = torch.clamp(cnt // 2, min=0, max=n - 1)
-    med = (srt.gather(0, lo[None, :]) + srt.gather(0, hi[None, :]))[0] / 2.0
-    med = torch.where(cnt > 0, med, torch.zeros_like(med))
-    return torch.where(bad, med[None, :].expand_as(X), X)
-
-
 def normalize_feature_device(X, method: str = "none", *, impute: str = "none", eps: float = DEFAULT_EPS,
                              device="cuda:0"):
     """`normalize_feature` on the GPU: X (n_items,) or (n_items, d) float64 (numpy array or torch tensor) ->
@@ -126,16 +109,20 @@ def normalize_feature_device(X, method: str = "none", *, impute: str = "none", e
     Xt = Xt.to(dev).contiguous()
     lib = _hip.load()
     with torch.cuda.device(dev):
-        if impute == "col_median":
-            Xt = _fill_with_col_median_device(Xt).contiguous()
         n, d = Xt.shape
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        work = torch.empty(3 * d, dtype=torch.float64, device=dev)
+        if impute == "col_median":          # in place on the device copy (the caller's array is never touched)
+            if Xt.data_ptr() == (X.data_ptr() if torch.is_tensor(X) else 0):
+                Xt = Xt.clone()
+            rc = lib.als_impute_col_median(n, d, C.c_void_p(Xt.data_ptr()), C.c_void_p(work.data_ptr()), stream)
+            if rc != 0:
+                raise RuntimeError(f"als_impute_col_median failed with status {rc}")
         out = torch.empty(n, d, dtype=torch.float32, device=dev)
-        work = torch.empty(2 * d, dtype=torch.float64, device=dev)
         status = torch.zeros(1, dtype=torch.int32, device=dev)
         rc = lib.als_normalize_features(n, d, C.c_void_p(Xt.data_ptr()), _METHOD_CODES[method], float(eps),
                                         C.c_void_p(out.data_ptr()), C.c_void_p(work.data_ptr()),
-                                        C.c_void_p(status.data_ptr()),
-                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+                                        C.c_void_p(status.data_ptr()), stream)
         if rc != 0:
             raise RuntimeError(f"als_normalize_features failed with status {rc}")
         if int(status.item()) & 1:

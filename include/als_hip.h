@@ -355,6 +355,10 @@ int als_graph_classify(int64_t n, int topk, const float* top_val, const int32_t*
  * ------------------------------------------------------------------------- */
 int als_normalize_features(int64_t n, int d, const double* X, int method, double eps, float* out,
                            double* colwork, int32_t* status, void* stream);
+/* Median imputation in place (scripts/prepare_features.py:82-92): every NaN / +-inf of X [n][d] (device, float64)
+ * becomes the median of its column's finite entries (mean of the two middle ones for an even count, 0 for a column
+ * without finite entries).  Exact order statistics by radix select; work: 3*d doubles. */
+int als_impute_col_median(int64_t n, int d, double* X, double* work, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Host-side set-up passes (HOST pointers, synchronous, no GPU involved).  They replace the reference's

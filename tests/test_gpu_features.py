@@ -88,3 +88,28 @@ def test_fit_takes_device_normalised_features():
     assert np.array_equal(a.U, b.U) and np.array_equal(a.V, b.V)
     assert all(np.array_equal(a.W[n], b.W[n]) for n in a.W)
     assert np.array_equal(a.predict_at(g.val_flat(), host), b.predict_at(g.val_flat(), devf))
+
+
+def test_device_median_imputation_against_numpy_at_size():
+    """als_impute_col_median (radix select): 200 001 x 7 with NaN / +-inf holes, an all-missing column, columns with an
+    even and an odd number of finite entries, duplicates and signed zeros - equal to numpy's nanmedian fill."""
+    import torch
+    from collaborative_filtering_amd import features as F
+    dev = _dev()
+    rng = np.random.default_rng(12)
+    n, d = 200_001, 7
+    X = np.round(rng.normal(size=(n, d)) * 50.0) / 8.0            # many duplicates
+    X[rng.random(size=(n, d)) < 0.2] = np.nan
+    X[::97, 1] = np.inf
+    X[5::89, 1] = -np.inf
+    X[:, 3] = np.nan                                             # all missing -> 0
+    X[:1000, 4] = -0.0
+    X[np.isnan(X[:, 5]), 5] = 1.0
+    X[0, 5] = np.nan                                             # exactly one hole: n - 1 = even count
+    want = F.normalize_feature(X, "none", impute="col_median", dtype="float64")
+    got = F.normalize_feature_device(X, "none", impute="col_median", device=dev)
+    assert np.array_equal(got.cpu().numpy(), want.astype(np.float32))
+    assert np.isnan(X).any()                                     # the caller's array is left alone
+    Xt = torch.from_numpy(X).to(dev)
+    F.normalize_feature_device(Xt, "col_zscore", impute="col_median", device=dev)
+    assert bool(torch.isnan(Xt).any())                           # ... also when it already lives on the device
