@@ -718,7 +718,8 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
             const int i = lane + 64 * rr;
             const int ic = min(i, KP - 1);
             const int colb = C::lcol_off_rt(ic >> 4) - 16 * (ic >> 4) * 16 + (c & 3);
-            for (int p = 0; p < KP; ++p) {
+#pragma unroll 8
+            for (int p = 0; p < KP; ++p) {      // (unrolled: the LDS reads of 8 rows in flight - one wave per SIMD at k > 96)
                 const int Jp = p >> 4;
                 const int rowv = max(ic, 16 * Jp);                                   // row i inside block column Jp
                 const float lrow = Ls[C::lcol_off_rt(Jp) + (rowv - 16 * Jp) * 16 +
