@@ -105,11 +105,11 @@ def test_row_solve_against_numpy(k, gram):
                                    atol=ga * max(np.max(np.abs(ref)), 1e-6))
 
 
-@pytest.mark.parametrize("k", [100, 112, 128])
+@pytest.mark.parametrize("k", [100, 112, 120, 128])
 def test_two_waves_per_row_kernel_against_numpy(k, monkeypatch):
     """row_pair.hip (opt-in, ALS_ROW_PAIR=1): same rows, same checks as the one-wave kernel - rows of 1 ... 8200
     ratings incl. the split path and the running totals of rows longer than 512 ratings, Gram by-product,
-    rhs_extra / diag_extra, padded columns (k = 100)."""
+    rhs_extra / diag_extra, padded columns (k = 100: KB = 7, k = 120: KB = 8)."""
     monkeypatch.setenv("ALS_ROW_PAIR", "1")
     test_row_solve_against_numpy(k, "bf16x3")
 
