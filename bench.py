@@ -257,67 +257,25 @@ def cpu_baseline(eng, budget_s=20.0):
                        f"loop is single-threaded")}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--size", default="cfg4", choices=sorted(SIZES))
-    ap.add_argument("--gs-mode", default=None, choices=[None, "exact", "block", "levels"],
-                    help="Laplacian sweep with several ranks: exact (default; shards in rank order), block, levels")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="debug only; not a valid headline run")
-    ap.add_argument("--hip-graph", action="store_true",
-                    help="replay iterations as captured HIP graphs (no per-phase timing; for launch-bound sizes)")
-    ap.add_argument("--gram", default="bf16x3", choices=["bf16x3", "f32"],
-                    help="how K1 forms the Gram: exact 3-way bf16 split on the bf16 matrix cores (fp32 "
-                         "accumulate, fp32-level accuracy) or v_mfma_f32 on the raw floats")
-    ap.add_argument("--graph", default="sampled", choices=["sampled", "product"],
-                    help="item graph: SURVEY 8(d)'s workload definition (default; every item's top-50 genre-cosine "
-                         "neighbours among 512 random candidates, symmetrised by max - the graph every number since "
-                         "round 1 was measured on), or the exact top-50 over ALL items built by the product's own "
-                         "kernels (csrc/graph_build.hip; 34 ms at n = 100K, 2.7 s at n = 1M - hub items with thousands "
-                         "of neighbours then lengthen the sweep: 2.7 instead of 1.4 ms at cfg 4)")
-    ap.add_argument("--solve-dtype", default="float32", choices=["float32", "float64"],
-                    help="float64: fp64 Gram / Cholesky / substitutions per row (accuracy mode; NOT the headline dtype)")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo: rehearsal of the N>1 code path with several ranks on ONE GPU")
-    args = ap.parse_args()
+def _sync(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    ngpu = torch.cuda.device_count()
-    local = local % max(ngpu, 1)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    # ALS_FORCE_COLLECTIVES=1: one-rank rehearsal of the sharded path and its RCCL calls on a single GPU
-    dist_on = world > 1 or os.environ.get("ALS_FORCE_COLLECTIVES") == "1"
-    if dist_on:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
-    if args.gpus != world and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
-    from collaborative_filtering_amd import ALS, ALSConfig, BiasesConfig, CoreConfig, GraphConfig, GraphSimConfig
-
-    m, n, nnz, k = SIZES[args.size]
-    t_setup = time.perf_counter()
-    # rank 0 generates, everybody receives the same bytes (robust against RNG differences)
-    use_graph = (not args.no_graph) and args.size not in ("cfg2", "cfg3")
-    features = gen_features(n, 3004) if args.size in ("cfg3", "cfg5-small", "cfg5") else None
+def make_inputs(size, dev, rank, dist_on, graph_kind="sampled", no_graph=False):
+    """Synthetic inputs of a named size, resident on `dev`: rank 0 generates, everybody receives the same bytes
+    (robust against RNG differences).  Returns (csr, csc, S, features, graph_build_s, seconds spent here)."""
+    m, n, nnz, k = SIZES[size]
+    t0 = time.perf_counter()
+    use_graph = (not no_graph) and size not in ("cfg2", "cfg3")
+    features = gen_features(n, 3004) if size in ("cfg3", "cfg5-small", "cfg5") else None
     graph_build_s = None
+    csr = csc = S = None
     if rank == 0:
         csr, csc = gen_ratings(dev, m, n, nnz, seed=1004)
         if not use_graph:
             S = None
-        elif args.graph == "product":
+        elif graph_kind == "product":
             S, graph_build_s = gen_graph_product(dev, n, seed=2004)
         else:
             S = gen_graph(dev, n, seed=2004)
@@ -340,34 +298,45 @@ def main():
                       enumerate([(torch.int64, n + 1), (torch.int32, NS), (torch.float32, NS)]))
         else:
             S = None
-    nnz = int(csr[1].numel())
+    _sync(dev)
+    return csr, csc, S, features, graph_build_s, time.perf_counter() - t0
 
-    n_total = args.warmup + args.steps
+
+def run_case(size, inputs, dev, *, steps, warmup, dist_on=False, gs_mode=None, gram="f16x2", hip_graph=False,
+             solve_dtype="auto", backend=None):
+    """Set the model up on resident inputs and time `steps` iterations after `warmup` (barrier + synchronize on
+    both sides, MAX over ranks).  Returns a dict: elapsed seconds, per-phase event times, the engine, set-up time
+    of the PRODUCT alone (upload / task lists / schedules / initial factors - no data generation)."""
+    from collaborative_filtering_amd import ALS, ALSConfig, BiasesConfig, CoreConfig, GraphConfig, GraphSimConfig
+    m, n, _, k = SIZES[size]
+    csr, csc, S, features = inputs[:4]
+    n_total = warmup + steps
     cfg = ALSConfig(core=CoreConfig(n_factors=k, n_iters=n_total, lambda_u=5.0, lambda_v=6.0, random_state=42,
-                                    pop_reg_mode="inverse_sqrt" if args.size in ("cfg5-small", "cfg5") else None),
+                                    pop_reg_mode="inverse_sqrt" if size in ("cfg5-small", "cfg5") else None),
                     biases=BiasesConfig(lambda_bu=3.0, lambda_bi=2.0),
                     graph=(GraphConfig(alpha=0.5, sim=GraphSimConfig(source="precomputed", topk=50))
                            if S is not None else GraphConfig()))
+    t_setup = time.perf_counter()
     model = ALS(cfg, lambda_w={"genres": 5.0, "years": 10.0} if features else None,
-                device=dev, gs_mode=args.gs_mode, gram=args.gram, hip_graph=args.hip_graph,
-                solve_dtype=args.solve_dtype, process_group="world" if dist_on else None)
+                device=dev, gs_mode=gs_mode, gram=gram, hip_graph=hip_graph, backend=backend,
+                solve_dtype=solve_dtype, process_group="world" if dist_on else None)
     eng = model.prepare_csr(csr, csc, (m, n), features=features, S=S)
     if features:
         eng.be.compose_z(eng.V, eng.Xcat, eng.Wcat, eng.Z)
-    torch.cuda.synchronize()
+    _sync(dev)
     t_setup = time.perf_counter() - t_setup
 
     def barrier():
         if dist_on:
             dist.barrier()
-        torch.cuda.synchronize()
+        _sync(dev)
 
-    for it in range(args.warmup):
+    for it in range(warmup):
         eng.iteration(it, n_total)
     barrier()
-    eng.timers = None if args.hip_graph else []       # event pairs cannot be recorded inside a captured graph
+    eng.timers = None if (hip_graph or dev.type != "cuda") else []   # event pairs cannot be recorded inside a captured graph
     t0 = time.perf_counter()
-    for it in range(args.warmup, n_total):
+    for it in range(warmup, n_total):
         eng.iteration(it, n_total)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -376,13 +345,86 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     eng._check_status()
-
-    # per-kernel times from the events recorded on the launch stream
     phase = {}
     for name, a, b in (eng.timers or []):
         phase.setdefault(name, []).append(a.elapsed_time(b))
     eng.timers = None
-    hist = eng.hist[: n_total].cpu().numpy()
+    return {"model": model, "eng": eng, "elapsed": elapsed, "phase": phase, "setup_s": t_setup,
+            "hist": eng.hist[: n_total].cpu().numpy()}
+
+
+def frac_iter_of(size, nnz, elapsed_per_step):
+    """[2 (4k+12) N + (m+n)(4k+12)] / t_iter as a fraction of 8 TB/s."""
+    m, n, _, k = SIZES[size]
+    return (2 * (4 * k + 12) * nnz + (m + n) * (4 * k + 12)) / elapsed_per_step / 1e9 / 8000.0
+
+
+def main(argv=None, *, backend=None, device=None):
+    """`backend` / `device`: test hook only (tests/test_dist_gloo.py runs this very code path on CPU ranks over gloo
+    with the test-only numpy stand-in); the command line always runs the HIP backend on cuda:LOCAL_RANK."""
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", default="cfg4", choices=sorted(SIZES))
+    ap.add_argument("--gs-mode", default=None, choices=[None, "exact", "block", "levels"],
+                    help="Laplacian sweep with several ranks: exact (default; shards in rank order), block, levels")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary cases (N = 1, cfg4 only)")
+    ap.add_argument("--no-graph", action="store_true", help="debug only; not a valid headline run")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="replay iterations as captured HIP graphs (no per-phase timing; for launch-bound sizes)")
+    ap.add_argument("--gram", default="f16x2", choices=["f16x2", "f32"],
+                    help="how K1 forms the Gram: 2-way fp16 split of the scaled floats on the fp16 matrix cores (fp32 "
+                         "accumulate, fp32-level accuracy) or v_mfma_f32 on the raw floats")
+    ap.add_argument("--graph", default="sampled", choices=["sampled", "product"],
+                    help="item graph: SURVEY 8(d)'s workload definition (default; every item's top-50 genre-cosine "
+                         "neighbours among 512 random candidates, symmetrised by max - the graph every number since "
+                         "round 1 was measured on), or the exact top-50 over ALL items built by the product's own "
+                         "kernels (csrc/graph_build.hip; 34 ms at n = 100K, 2.7 s at n = 1M - hub items with thousands "
+                         "of neighbours then lengthen the sweep: 2.7 instead of 1.4 ms at cfg 4)")
+    ap.add_argument("--solve-dtype", default="auto", choices=["auto", "float32", "float64"],
+                    help="auto (the product's default): fp32 rows, ill-conditioned rows redone in fp64; float64: fp64 "
+                         "Gram / Cholesky / substitutions for every row (accuracy mode; NOT the headline dtype)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N>1 code path with several ranks on ONE GPU")
+    args = ap.parse_args(argv)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if device is None:
+        ngpu = torch.cuda.device_count()
+        local = local % max(ngpu, 1)
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    else:
+        dev = torch.device(device)
+    # ALS_FORCE_COLLECTIVES=1: one-rank rehearsal of the sharded path and its RCCL calls on a single GPU
+    dist_on = world > 1 or os.environ.get("ALS_FORCE_COLLECTIVES") == "1"
+    own_group = False
+    if dist_on and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if args.dist_backend == "nccl" and dev.type == "cuda":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+        own_group = True
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    m, n, nnz, k = SIZES[args.size]
+    inputs = make_inputs(args.size, dev, rank, dist_on, args.graph, args.no_graph)
+    csr, csc, S, features, graph_build_s, datagen_s = inputs
+    use_graph = S is not None
+    nnz = int(csr[1].numel())
+    n_total = args.warmup + args.steps
+    res = run_case(args.size, inputs, dev, steps=args.steps, warmup=args.warmup, dist_on=dist_on, gs_mode=args.gs_mode,
+                   gram=args.gram, hip_graph=args.hip_graph, solve_dtype=args.solve_dtype, backend=backend)
+    eng, elapsed, phase, hist, t_setup = res["eng"], res["elapsed"], res["phase"], res["hist"], res["setup_s"]
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
@@ -416,16 +458,16 @@ def main():
                                     "frac": (4 * k + 12) * (nn + rr) / (1e-3 * sum(phase.get(nm, [1e-9])) / args.steps) / 1e9 / 8000.0}
                                for nm, nn, rr in (("row_solve_user", nn_u, rows_u), ("row_solve_item", nn_i, rows_i))},
                 "traffic": None}
-        # matrix-core view: flops the kernel actually ISSUES.  bf16x3 mode: the 10 of 16 lower Gram blocks, six
-        # bf16 MFMAs per block (exact 3-way split) -> 6 * (10/16) * 2 k^2 flops per rating, against the dense bf16
+        # matrix-core view: flops the kernel actually ISSUES.  f16x2 mode: the 10 of 16 lower Gram blocks, three
+        # fp16 MFMAs per block (2-way split) -> 3 * (10/16) * 2 k^2 flops per rating, against the dense fp16 / bf16
         # peak; f32 mode: (10/16) * 2 k^2 on v_mfma_f32 against the fp32 matrix peak.  (For k != 64 the block count
         # is KB(KB+1)/2 of KB^2.)
         kb = -(-k // 16)
         sym = (kb * (kb + 1) / 2) / (kb * kb)
         if args.solve_dtype == "float64":
             issued, peak_tf, what = sym * 2 * (16 * kb) ** 2 * (nn_u + nn_i), 78.6, "fp64 MFMA flops issued / dense fp64 matrix peak"
-        elif args.gram == "bf16x3":
-            issued, peak_tf, what = 6 * sym * 2 * (16 * kb) ** 2 * (nn_u + nn_i), 2500.0, "bf16 MFMA flops issued (6 per Gram product) / dense bf16 peak"
+        elif args.gram == "f16x2":
+            issued, peak_tf, what = 3 * sym * 2 * (16 * kb) ** 2 * (nn_u + nn_i), 2500.0, "fp16 MFMA flops issued (3 per Gram product) / dense fp16 peak"
         else:
             issued, peak_tf, what = sym * 2 * (16 * kb) ** 2 * (nn_u + nn_i), 157.3, "fp32 MFMA flops issued / dense fp32 matrix peak"
         roof["mfma_view"] = {"issued_TFLOPs": issued / t_rs / 1e12, "peak_TFLOPs": peak_tf,
@@ -435,7 +477,7 @@ def main():
         # (profiles/collect_pmc.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
         import glob
         pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_k_row_tasks.json")))
-        if pm and args.size == "cfg4" and world == 1 and args.solve_dtype == "float32":
+        if pm and args.size == "cfg4" and world == 1 and args.solve_dtype != "float64":
             roof["traffic"] = json.load(open(pm[-1]))["traffic_bytes_per_launch_mean"]
             roof["traffic_source"] = "from_profile: " + os.path.relpath(pm[-1], ROOT) + " (not measured in this run)"
         out = {
@@ -443,8 +485,8 @@ def main():
             "unit": "ratings/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": ("f32 storage; f64 Gram / Cholesky / substitutions (solve_dtype=float64)" if args.solve_dtype == "float64"
-                      else "f32 (storage, solve, accumulate); Gram products as exact 3-way bf16 split on bf16 MFMA"
-                      if args.gram == "bf16x3" else "f32"), "data": "synthetic",
+                      else "f32 (storage, solve, accumulate); Gram products as 2-way fp16 split (error <= 2^-23) on fp16 MFMA"
+                      if args.gram == "f16x2" else "f32"), "data": "synthetic",
             "config": {"workload": f"{args.size}: {m} users x {n} items, {nnz} ratings, k={k}, bias + "
                                    f"graph-Laplacian (alpha=0.5, {0 if S is None else int(S[1].numel())} graph nnz)"
                                    + (" [BASELINE.json configs[3]]" if args.size == "cfg4" else ""),
@@ -452,17 +494,57 @@ def main():
                        if eng.use_graph else 0,
                        "parallelism": f"users/items sharded x{world}, all-gather of factor blocks",
                        "graph": args.graph if use_graph else None, "graph_build_s": graph_build_s,
-                       "setup_s": t_setup},
+                       # set-up of the PRODUCT (upload, task lists, level schedule, initial factors) and the generation
+                       # of the synthetic inputs, timed separately; both are outside `value`
+                       "setup_s": t_setup, "datagen_s": datagen_s},
             "phase_ms_per_step": {kk: sum(v) / args.steps for kk, v in phase.items()},
             "train_rmse": [float(x) for x in hist[:, 0]],
             "roofline": roof if not args.hip_graph else None,   # per-launch times need the eager path
         }
+        if eng.use_graph and getattr(eng, "gs_mode", None) == "exact":
+            # what the exact (reference-order) Gauss-Seidel sweep allows at most on N GPUs: the sweep is a dependency
+            # chain that takes the same time on any number of GPUs, everything else divides by N (DESIGN.md section 6;
+            # from THIS run's one-GPU phase times when N = 1, otherwise stated as unknown)
+            if world == 1 and phase.get("gs_sweep"):
+                t_sw = sum(phase["gs_sweep"]) / args.steps
+                out["config"]["scaling_cap"] = {
+                    "mode": "exact", "sweep_ms": t_sw,
+                    "speedup_bound_at_8_gpus": ms_step / (t_sw + (ms_step - t_sw) / 8.0),
+                    "note": "serial sweep + everything else / N, exchanges not counted; north_star asks >= 6x"}
+            else:
+                out["config"]["scaling_cap"] = {"mode": "exact", "note": "the sweep's dependency chain does not shrink "
+                                                "with N; see the N = 1 line for the bound"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(eng)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        if (world == 1 and not dist_on and args.size == "cfg4" and not args.no_secondary and not args.hip_graph
+                and args.solve_dtype == "auto" and backend is None):
+            # other shapes / the reference's arithmetic type, in the driver's record as well (each a few seconds):
+            # same code path, fewer steps; ms_per_step and the SURVEY 8(d) iteration fraction
+            del res, eng
+            sec = {}
+            r64 = run_case("cfg4", inputs, dev, steps=3, warmup=1, solve_dtype="float64")
+            sec["cfg4_float64"] = {"ms_per_step": 1e3 * r64["elapsed"] / 3, "frac_iter": frac_iter_of("cfg4", nnz, r64["elapsed"] / 3),
+                                   "setup_s": r64["setup_s"], "what": "headline workload with solve_dtype=float64 everywhere"}
+            del r64, inputs, csr, csc, S
+            torch.cuda.empty_cache()
+            for sz, what in (("cfg5-small", "BASELINE configs[4] shape / 50: k = 128, bias + W_f + Laplacian, popularity-scaled lambda_v"),
+                             ("cfg3", "BASELINE configs[2]: 138K x 27K, 20M ratings, k = 64, + W_f genres / years")):
+                inp = make_inputs(sz, dev, 0, False)
+                rr = run_case(sz, inp, dev, steps=5, warmup=2)
+                nz = int(inp[0][1].numel())
+                sec[sz] = {"ms_per_step": 1e3 * rr["elapsed"] / 5, "frac_iter": frac_iter_of(sz, nz, rr["elapsed"] / 5),
+                           "ratings_per_s": nz / (rr["elapsed"] / 5), "setup_s": rr["setup_s"], "datagen_s": inp[5],
+                           "phase_ms_per_step": {kk: sum(v) / 5 for kk, v in rr["phase"].items()}, "what": what}
+                del inp, rr
+                torch.cuda.empty_cache()
+            out["secondary"] = sec
         print(json.dumps(out))
-    if dist_on:
+    else:
+        out = None
+    if own_group:
         dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

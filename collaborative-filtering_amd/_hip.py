@@ -17,7 +17,7 @@ SPLIT_CHUNK = 4096          # ALS_SPLIT_CHUNK
 MAX_K = 160                 # ALS_MAX_K
 
 EXPORTS = ("als_version", "als_padded_k", "als_perm_index", "als_partial_slot_bytes", "als_partial_slot_bytes_f64",
-           "als_row_solve", "als_row_solve_scratch_bytes", "als_gs_sweep", "als_gs_sweep_levels", "als_gs_sweep_dataflow", "als_residual_stats", "als_w_normal_equations", "als_spd_solve_workspace_bytes", "als_spd_solve_f64", "als_item_stats", "als_sum_pairs", "als_sumsq_partials",
+           "als_row_solve", "als_factor_scale", "als_gs_sweep", "als_gs_sweep_levels", "als_gs_sweep_dataflow", "als_residual_stats", "als_w_normal_equations", "als_spd_solve_workspace_bytes", "als_spd_solve_f64", "als_item_stats", "als_item_stats_f64", "als_sum_pairs", "als_sumsq_partials",
            "als_sumsq", "als_history_row", "als_compose_z", "als_predict_at", "als_predict_dense",
            "als_topk_similarity", "als_graph_classify", "als_normalize_features", "als_impute_col_median",
            "als_host_coo_to_sides", "als_host_row_tasks", "als_host_level_schedule")
@@ -29,7 +29,7 @@ class RowSolveParams(C.Structure):
     """struct als_row_solve_params (include/als_hip.h)."""
     _fields_ = [
         ("k", _i32), ("ld", _i32), ("nrows", _i64), ("F_zero_row", _i32), ("reserved0", _i32),
-        ("gram_mode", _i32), ("ndual_tail", _i32), ("ndual_mid", _i32), ("reserved1", _i32),
+        ("gram_mode", _i32), ("ndual_tail", _i32), ("ndual_mid", _i32), ("F_scale_ready", _i32),
         ("indptr", _vp), ("indices", _vp), ("vals", _vp), ("F", _vp),
         ("bias_self", _vp), ("bias_other", _vp), ("mu", _vp),
         ("lambda_scalar", _f32), ("lambda_row", _vp),
@@ -39,7 +39,8 @@ class RowSolveParams(C.Structure):
         ("rhs_out", _vp), ("colsum_out", _vp), ("sumr_out", _vp), ("sumr2_out", _vp), ("stat_out", _vp),
         ("status", _vp),
         ("tasks", _vp), ("ntasks", _i64), ("long_rows", _vp), ("nlong", _i64),
-        ("workspace", _vp), ("scratch", _vp),
+        ("workspace", _vp), ("cond_limit", _f32), ("byproducts_f64", _i32), ("redo_count", _vp), ("redo_rows", _vp),
+        ("cond_out", _vp), ("F_scale", _vp),
     ]
 
 
@@ -51,6 +52,7 @@ class GsSweepParams(C.Structure):
         ("factor", _vp), ("rhs", _vp), ("colsum", _vp), ("sumr", _vp),
         ("indptr", _vp), ("lambda_bias_scalar", _f32), ("lambda_bias_row", _vp),
         ("V", _vp), ("bias", _vp), ("sumr2", _vp), ("lambda_eff", _vp), ("stat_out", _vp),
+        ("f64", _i32), ("reserved", _i32),
     ]
 
 
@@ -60,7 +62,7 @@ class WParams(C.Structure):
         ("k", _i32), ("ld", _i32), ("phase", _i32), ("nfeat", _i32),
         ("item_begin", _i64), ("item_end", _i64),
         ("gram", _vp), ("rhs", _vp), ("colsum", _vp), ("V", _vp), ("b_new", _vp), ("b_old", _vp),
-        ("D", _i32), ("reserved", _i32), ("X", _vp), ("feat_off", _vp), ("W", _vp), ("H", _vp),
+        ("D", _i32), ("f64", _i32), ("X", _vp), ("feat_off", _vp), ("W", _vp), ("H", _vp),
         ("nrows_h", _i64),
         ("feat_index", _i32), ("feat_col0", _i32), ("feat_d", _i32), ("nchunks", _i32),
         ("partA", _vp), ("partB", _vp), ("A_out", _vp), ("B_out", _vp),
@@ -95,8 +97,7 @@ def load():
     lib.als_partial_slot_bytes_f64.argtypes = [C.c_int]
     lib.als_partial_slot_bytes_f64.restype = _i64
     lib.als_row_solve.argtypes = [C.POINTER(RowSolveParams), _vp]
-    lib.als_row_solve_scratch_bytes.argtypes = [C.c_int]
-    lib.als_row_solve_scratch_bytes.restype = _i64
+    lib.als_factor_scale.argtypes = [_vp, _i64, _vp, _vp]
     lib.als_gs_sweep.argtypes = [C.POINTER(GsSweepParams), _vp]
     lib.als_gs_sweep_levels.argtypes = [C.POINTER(GsSweepParams), _vp, _i64, _vp]
     lib.als_gs_sweep_dataflow.argtypes = [C.POINTER(GsSweepParams), _vp, _vp, _i64, _vp, _vp, _vp]
@@ -105,6 +106,7 @@ def load():
     lib.als_w_normal_equations.argtypes = [C.POINTER(WParams), _vp]
     lib.als_sumsq_partials.restype = C.c_int
     lib.als_item_stats.argtypes = [C.c_int, C.c_int, _i64, _i64] + [_vp] * 11
+    lib.als_item_stats_f64.argtypes = [C.c_int, C.c_int, _i64, _i64] + [_vp] * 11
     lib.als_spd_solve_workspace_bytes.argtypes = [_i64]
     lib.als_spd_solve_f64.argtypes = [_i64, _vp, _i64, _vp, C.c_double, _vp, _vp, _vp, _vp]
     lib.als_sumsq.argtypes = [_vp, _i64, _vp, _vp, _vp]
@@ -121,8 +123,7 @@ def load():
     lib.als_host_row_tasks.argtypes = [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp]
     lib.als_host_level_schedule.argtypes = [_i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]
     for name in EXPORTS:
-        if name not in ("als_partial_slot_bytes", "als_partial_slot_bytes_f64", "als_spd_solve_workspace_bytes",
-                        "als_row_solve_scratch_bytes"):
+        if name not in ("als_partial_slot_bytes", "als_partial_slot_bytes_f64", "als_spd_solve_workspace_bytes"):
             getattr(lib, name).restype = C.c_int
     lib.als_spd_solve_workspace_bytes.restype = C.c_size_t
     _lib = lib

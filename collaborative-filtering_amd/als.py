@@ -31,6 +31,7 @@ from .als_config import ALSConfig
 
 SCALE_FACTOR = 0.1      # scripts/als.py:93
 EPS = 1e-10             # scripts/als.py:94
+W_F64_BELOW = 1e-2      # solve_dtype="auto": fp64 V-step by-products when some lambda_w (+ 1e-10) is below this
 
 logger = logging.getLogger(__name__)
 
@@ -39,6 +40,11 @@ logger = logging.getLogger(__name__)
 # content.  Two entries: a dense n x n float32 S is 99 MB at n = 4980.
 _SIM_CACHE: "dict" = {}
 _SIM_CACHE_MAX = 2
+
+# Devices on which the persistent one-launch sweep has given up once (SweepNotResident: something else holds compute
+# units there): later fits in this process start with the per-level launches instead of paying a failed attempt
+# each - a sweep driver makes a new ALS per fit.
+_DATAFLOW_GAVE_UP: "set" = set()
 
 
 def _similarity_cached(X: np.ndarray, topk, eps):
@@ -152,6 +158,7 @@ class _RowShift:
 
     def __init__(self, t: torch.Tensor, row0: int, row_elems: int):
         self.t, self.row0, self.row_elems = t, int(row0), int(row_elems)
+        self.base = t                   # the tensor that exists (an attribute no torch.Tensor has)
 
     def data_ptr(self) -> int:
         return self.t.data_ptr() - self.row0 * self.row_elems * self.t.element_size()
@@ -232,7 +239,7 @@ class ALS:
     def __init__(self, config: ALSConfig, lambda_w: Optional[Dict[str, float]] = None, *,
                  device=None, backend=None, gs_mode: Optional[str] = None, process_group=None,
                  gram: Optional[str] = None, graph_build: str = "host", hip_graph: bool = False,
-                 solve_dtype: str = "float32", fit_cache: Optional["FitCache"] = None) -> None:
+                 solve_dtype: str = "auto", fit_cache: Optional["FitCache"] = None) -> None:
         if config is None:                                   # scripts/als.py:146-147
             raise ValueError("ALSConfig must be provided.")
         self.cfg = config
@@ -263,12 +270,12 @@ class ALS:
         self._backend = backend
         self._gs_mode = gs_mode
         self._pg = process_group
-        self._gram = gram               # "bf16x3" (default) or "f32": how K1 forms the Gram on the matrix cores
+        self._gram = gram               # "f16x2" (default) or "f32": how K1 forms the Gram on the matrix cores
         # "float64": every row's normal equations are accumulated, factorised and solved in fp64 (the reference's
         # arithmetic type) - for the small-lambda corner of the tuner's search space, where rank-deficient rows
         # have cond ~ 1/lambda; factors stay fp32 in HBM.  Several times slower than fp32.
-        if solve_dtype not in ("float32", "float64"):
-            raise ValueError("solve_dtype must be 'float32' or 'float64'")
+        if solve_dtype not in ("auto", "float32", "float64"):
+            raise ValueError("solve_dtype must be 'auto', 'float32' or 'float64'")
         self._solve_dtype = solve_dtype
         if graph_build not in ("host", "device"):
             raise ValueError("graph_build must be 'host' (reference-identical, dense n x n) or 'device'")
@@ -360,7 +367,7 @@ class ALS:
         backend = self._backend
         if backend is None:
             from .backend import HipBackend
-            backend = HipBackend(device, gram=self._gram or "bf16x3", solve_dtype=self._solve_dtype)
+            backend = HipBackend(device, gram=self._gram or "f16x2", solve_dtype=self._solve_dtype)
         with _on(device):
             self._eng = _Engine(self, csr, csc, features, S_csr, device, backend, self._pg, self._gs_mode)
         if not run:                         # prepare(): the caller drives the iterations
@@ -379,6 +386,7 @@ class ALS:
                 # dependency level (stream order is the only synchronisation they need)
                 logger.warning("%s; refitting with per-level sweep launches", e)
                 self._dataflow_sweep = False
+                _DATAFLOW_GAVE_UP.add(str(device))
                 self._eng = _Engine(self, csr, csc, features, S_csr, device, backend, self._pg, self._gs_mode)
                 self._eng.run(tol, min_iters, verbose)
             self._eng.export(self)
@@ -465,6 +473,15 @@ class _Engine:
         self.feat_names = list(features)
         self.feat_dims = [int(features[f].shape[1]) for f in self.feat_names]
         init_key = ("init", model.random_state, self.m, self.n, k, tuple(self.feat_dims))
+        # The V-step in fp64 with fp64 by-products (item Grams, right-hand sides, Cholesky factors, column sums) for
+        # the W-step / the sweep / the item statistics: always under solve_dtype="float64"; under "auto" when a
+        # feature's ridge parameter is (nearly) absent - lambda_w missing means 0 (scripts/als.py:497) - because the
+        # (d k)^2 system is then singular up to the 1e-10 the reference adds and normal equations assembled from
+        # fp32 Grams (rounding ~3e-7 |A|) are no longer positive definite, let alone accurate.
+        lw_min = min((float(model.lambda_w.get(f, 0.0)) for f in self.feat_names), default=float("inf"))
+        mode = getattr(backend, "solve_dtype", "float32")
+        self.v_f64 = bool(getattr(backend, "lib", None) is not None and
+                          (mode == "float64" or (mode == "auto" and lw_min + EPS < W_F64_BELOW)))
 
         def draw_init_host():
             rng = np.random.default_rng(model.random_state)
@@ -486,12 +503,14 @@ class _Engine:
         uptr_h = cache.get(("indptr_h", ku), lambda: self.csr.indptr.cpu().numpy())
         iptr_h = cache.get(("indptr_h", ki), lambda: self.csc.indptr.cpu().numpy())
 
-        # --- shards: contiguous row ranges balanced by number of ratings; every rank derives the same
-        # tables from the row pointers.  The user shard is solved in u_chunks sub-ranges whose all-gathers overlap
+        # --- shards: contiguous row ranges balanced by predicted cost = ratings + c(k) * rows (about
+        # half of a U-step row's time at cfg 4 is per row, not per rating, so rating-balanced shards of a skewed input
+        # would be time-imbalanced); every rank derives the same tables from the row pointers.  The user shard is solved in u_chunks sub-ranges whose all-gathers overlap
         # the next sub-range's solve.  Factor storage is exactly [rows + 1, ld] (the extra row is the zero row).
         self.u_chunks = max(1, int(os.environ.get("ALS_U_CHUNKS", self.U_CHUNKS))) if self.multi else 1
-        self.ubounds, self.uchunks = layout.shard_bounds_nnz(uptr_h, self.world, self.u_chunks)
-        self.ibounds, _ = layout.shard_bounds_nnz(iptr_h, self.world)
+        self.row_cost = layout.row_cost_weight(k)
+        self.ubounds, self.uchunks = layout.shard_bounds_nnz(uptr_h, self.world, self.u_chunks, self.row_cost)
+        self.ibounds, _ = layout.shard_bounds_nnz(iptr_h, self.world, 1, self.row_cost)
         self.ub, self.ue = self.ubounds[self.rank]
         self.ib, self.ie = self.ibounds[self.rank]
         m_pad, n_pad = self.m, self.n
@@ -513,8 +532,8 @@ class _Engine:
         if self.u_chunks > 1:
             self.utasks_c = [tasks_dev(ku, uptr_h, b, e) for b, e in self.uchunks[self.rank]]
         nslots = max(self.utasks.nslots, self.itasks.nslots)
-        self.workspace = (torch.empty(nslots * backend.slot_bytes(k) // 4, dtype=f32, device=device)
-                          if nslots else None)
+        slot_bytes = max(backend.slot_bytes(k), backend.slot_bytes(k, True) if self.v_f64 else 0)
+        self.workspace = (torch.empty(nslots * slot_bytes // 4, dtype=f32, device=device) if nslots else None)
         # Everything the host reads back per iteration lives in ONE 128-byte block: the history row (6 doubles at
         # byte 0) and the three status words (int32 at byte 64: row-solve status, sweep error, W-step status) - early
         # stopping then costs a single contiguous device-to-host copy per iteration instead of four small ones.
@@ -522,6 +541,7 @@ class _Engine:
         self.hist_row = self.ctrl[0:48].view(f64)
         words = self.ctrl[64:128].view(torch.int32)
         self.status, self.gs_err_word, self.w_bad = words[0:1], words[1:2], words[2:3]
+        self.status_words = words[0:4]
 
         # --- parameters (scripts/als.py:329,360-376): numpy Generator on the host, same draw order
         mean0 = cache.get(("mean", ku), lambda: float(self.csr.vals.to(f64).mean().item()) if self.nnz
@@ -550,7 +570,6 @@ class _Engine:
                          for f in self.feat_names})
             fkey = ("features", tuple((f, cache.pin(features[f])) for f in self.feat_names), n_pad)
             self.Xcat, self.X64 = cache.get(fkey, upload_features)
-            self._feat_key = tuple((f, id(features[f])) for f in self.feat_names)
             self.Wcat = torch.zeros(self.Xcat.shape[1], self.ld, dtype=f32, device=device)
             self.Z = torch.zeros(n_pad + 1, self.ld, dtype=f32, device=device)[:n_pad]
             self._sync_wcat()
@@ -607,7 +626,8 @@ class _Engine:
                 raise ValueError(f"unknown gs_mode '{self.gs_mode}'")
             active = counts > 0
             # persistent dataflow sweep (one launch, no level barriers) when the backend has it
-            self.gs_dataflow = (hasattr(backend, "gs_dataflow") and model._dataflow_sweep
+            self.gs_dataflow = (hasattr(backend, "gs_dataflow") and model._dataflow_sweep and not self.v_f64
+                                and str(device) not in _DATAFLOW_GAVE_UP
                                 and not (self.multi and self.gs_mode == "levels"))
             lo, hi = (0, self.n) if (self.multi and self.gs_mode == "levels") else (self.ib, self.ie)
 
@@ -642,8 +662,10 @@ class _Engine:
         self.local_rows = (self.ib, self.ie - self.ib) if lib is not None else (0, n_pad)
         r0, nloc = self.local_rows
 
-        def local(*row_shape):
-            t = torch.zeros((nloc,) + row_shape, dtype=f32, device=device)
+        byp = f64 if self.v_f64 else f32           # dtype of the V-step by-products
+
+        def local(*row_shape, dtype=None):
+            t = torch.zeros((nloc,) + row_shape, dtype=dtype or byp, device=device)
             return _RowShift(t, r0, int(np.prod(row_shape)) if row_shape else 1) if lib is not None else t
 
         if self.use_graph:
@@ -657,13 +679,13 @@ class _Engine:
         # --- fused statistics (DESIGN.md "Statistics"): without features Z == V, so the residual
         #     sums of an iteration follow in closed form from what the V-step already holds
         self.fused_stats = ((not self.feat_names) and hasattr(backend, "sum_pairs")
-                            and (self.ld <= 64 or not self.use_graph or getattr(self, "gs_dataflow", False)))
+                            and (self.ld <= 64 or not self.use_graph or getattr(self, "gs_dataflow", False) or self.v_f64))
         # with features Z != V: the same sums follow per item from the V-step's Gram / rhs / column sums
         # and the final Z (als_item_stats), again without a pass over the ratings
         self.fused_feat_stats = (bool(self.feat_names) and hasattr(backend, "item_stats")
                                  and hasattr(backend, "sum_pairs"))
         if self.fused_stats or self.fused_feat_stats:
-            self.stat_rows = local(2)
+            self.stat_rows = local(2, dtype=f32)
             if self.use_graph or self.fused_feat_stats:
                 self.sumr2 = local()
             if self.use_graph:
@@ -675,6 +697,7 @@ class _Engine:
         self.ss = torch.zeros(4, dtype=f64, device=device)
         self.hist = torch.zeros(max(model.n_iters, 1), 6, dtype=f64, device=device)
         self._graphs = {}
+        self._stage = {}                # receive buffers of _allgather_rows, one per (tensor, rows per rank)
         self.graphs_captured = 0
         self.replay_ok = True           # (diagnostics: set False to force eager iterations)
         self.iters_run = 0
@@ -693,27 +716,34 @@ class _Engine:
             self.Wcat[off:off + d, : self.k] = self.W64[f].to(torch.float32)
             off += d
 
-    def _allgather_rows(self, t: torch.Tensor, bounds, async_op: bool = False):
+    def _allgather_rows(self, t: torch.Tensor, bounds, async_op: bool = False, tag=None):
         """All-gather of the contiguous, unevenly sized row shards `bounds[r] = (begin, end)` of `t`: every rank
-        contributes its rows padded to the longest shard (one all_gather_into_tensor - RCCL and gloo both need
-        equal sizes), `finish()` copies the other ranks' rows into place.  Returns finish (called at once unless
-        async_op)."""
+        contributes `per` rows (the longest shard) in one all_gather_into_tensor - RCCL and gloo both need equal
+        sizes -, `finish()` copies the other ranks' rows into place (`tag` keeps exchanges that are in flight
+        together - the sub-ranges of the U-step - on separate receive buffers).  No staging copy of the own rows: rank r sends
+        the window t[s_r : s_r + per] with s_r = min(begin_r, rows - per), which contains its shard (what else is
+        in the window is ignored by the receivers).  The receive buffer is allocated once per (tensor, per).
+        Returns finish (called at once unless async_op)."""
         if not self.multi:
             return None
-        b, e = bounds[self.rank]
-        per = max(max(hi - lo for lo, hi in bounds), 1)
+        rows = t.shape[0]
+        per = min(max(max(hi - lo for lo, hi in bounds), 1), rows)
+        starts = [min(lo, rows - per) for lo, _ in bounds]
         tail = tuple(t.shape[1:])
-        mine = torch.zeros((per,) + tail, dtype=t.dtype, device=t.device)
-        mine[: e - b] = t[b:e]
-        stage = torch.empty((self.world, per) + tail, dtype=t.dtype, device=t.device)
-        work = dist.all_gather_into_tensor(stage.view(-1), mine.view(-1), group=self.pg, async_op=async_op)
+        key = (tag, t.data_ptr(), per, tail, t.dtype)
+        stage = self._stage.get(key)
+        if stage is None:
+            stage = self._stage[key] = torch.empty((self.world, per) + tail, dtype=t.dtype, device=t.device)
+        s0 = starts[self.rank]
+        work = dist.all_gather_into_tensor(stage.view(-1), t[s0:s0 + per].reshape(-1), group=self.pg,
+                                           async_op=async_op)
 
         def finish():
             if work is not None:
                 work.wait()
             for r, (lo, hi) in enumerate(bounds):
                 if r != self.rank and hi > lo:
-                    t[lo:hi] = stage[r, : hi - lo]
+                    t[lo:hi] = stage[r, lo - starts[r]: hi - starts[r]]
         if async_op:
             return finish
         finish()
@@ -727,7 +757,12 @@ class _Engine:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
 
     def _read_ctrl(self):
-        """(history row, status words) of the last iteration: one contiguous 128-byte device-to-host copy."""
+        """(history row, status words) of the last iteration: one contiguous 128-byte device-to-host copy.
+        With several ranks the status words are first reduced (MAX) over the group, so that every rank takes the
+        same decision - all raise LinAlgError / SweepNotResident (and refit) together, or none does; a rank that
+        left the iteration loop alone would leave the others waiting in their next collective."""
+        if self.multi:
+            dist.all_reduce(self.status_words, op=dist.ReduceOp.MAX, group=self.pg)
         c = self.ctrl.cpu()
         return c[0:48].view(torch.float64).numpy(), c[64:76].view(torch.int32).numpy()
 
@@ -790,8 +825,8 @@ class _Engine:
                 if self.utasks_c[c].ntasks or self.utasks_c[c].nlong:
                     self.be.row_solve(tasks=self.utasks_c[c], **kw)
                 cb = [self.uchunks[r][c] for r in range(self.world)]        # sub-range c of every rank's shard
-                pending.append(self._allgather_rows(self.U, cb, async_op=True))
-                pending.append(self._allgather_rows(self.b_u, cb, async_op=True))
+                pending.append(self._allgather_rows(self.U, cb, async_op=True, tag=c))
+                pending.append(self._allgather_rows(self.b_u, cb, async_op=True, tag=c))
         with self._tick("allgather_user_wait"):
             for finish in pending:
                 finish()
@@ -807,7 +842,7 @@ class _Engine:
                       bias_other=self.b_u, mu=self.mu, lam=0.0, lam_row=self.lam_v_row,
                       lam_b=md.lambda_bi, lam_b_row=None, rhs_extra=None,
                       gram_out=self.gram if want_gram else None, status=self.status,
-                      tasks=self.itasks, workspace=self.workspace)
+                      tasks=self.itasks, workspace=self.workspace, **({"f64": True} if self.v_f64 else {}))
         if not self.use_graph:
             with self._tick("row_solve_item"):
                 self.be.row_solve(diag_extra=None, X_out=self.V, bias_out=self.b_i, factor_out=None,
@@ -852,6 +887,8 @@ class _Engine:
                   V=self.V, bias=self.b_i)
         if self.fused_stats:
             kw.update(sumr2=self.sumr2, lambda_eff=self.lam_eff, stat_out=self.stat_rows)
+        if self.v_f64:
+            kw.update(f64=True)
         if self.gs_dataflow:
             self.be.gs_dataflow(items=self.sched_items, S_idx_wait=self.S_idx_wait, publish=self.gs_publish,
                                 err=self.gs_err, nondep=self.gs_nondep, **kw)
@@ -915,20 +952,23 @@ class _Engine:
         k, ld = self.k, self.ld
         if not hasattr(self, "H"):
             r0, nloc = self.local_rows
-            H = torch.zeros(len(self.feat_names), nloc, ld, dtype=torch.float32, device=self.dev)
+            H = torch.zeros(len(self.feat_names), nloc, ld, dtype=torch.float64 if self.v_f64 else torch.float32,
+                            device=self.dev)
             self.H = _RowShift(H, r0, ld) if r0 or nloc != self.n_pad else H
             offs = np.concatenate([[0], np.cumsum(self.feat_dims)]).astype(np.int32)
             self.feat_off_host = offs
             self.feat_off = torch.from_numpy(offs).to(self.dev)
             self.w_status = torch.zeros(1, dtype=torch.int32, device=self.dev)    # (w_bad: sticky, in self.ctrl)
+        f64kw = {"f64": True} if self.v_f64 else {}
+        Wold = torch.cat([self.W64[f] for f in self.feat_names], dim=0).contiguous() if self.v_f64 else self.Wcat
         self.be.w_item_vectors(k=k, ld=ld, item_begin=self.ib, item_end=self.ie, gram=self.gram,
                                rhs=self.rhs_out, colsum=self.colsum_out, V=self.V, b_new=self.b_i,
-                               b_old=b_i_old, X=self.Xcat, feat_off=self.feat_off, W=self.Wcat, H=self.H)
+                               b_old=b_i_old, X=self.Xcat, feat_off=self.feat_off, W=Wold, H=self.H, **f64kw)
         newW = {}
         for fi, (f, d) in enumerate(zip(self.feat_names, self.feat_dims)):
             A_full, B_full = self.be.w_accumulate(k=k, ld=ld, item_begin=self.ib, item_end=self.ie,
                                                   gram=self.gram, X=self.Xcat, H=self.H, feat_index=fi,
-                                                  feat_col0=int(self.feat_off_host[fi]), feat_d=d)
+                                                  feat_col0=int(self.feat_off_host[fi]), feat_d=d, **f64kw)
             if self.multi:
                 self._allreduce(A_full)
                 self._allreduce(B_full)
@@ -951,7 +991,7 @@ class _Engine:
                 self.be.item_stats(k=self.k, ld=self.ld, item_begin=self.ib, item_end=self.ie, gram=self.gram,
                                    rhs=self.rhs_out, colsum=self.colsum_out, sumr=self.sumr, sumr2=self.sumr2,
                                    indptr=self.csc.indptr, Z=self.Z, b_new=self.b_i, b_old=self.b_i_prev,
-                                   stat_out=self.stat_rows)
+                                   stat_out=self.stat_rows, **({"f64": True} if self.v_f64 else {}))
                 self.be.sum_pairs(self.stat_rows, self.stats)
             else:
                 self.be.residual_stats(k=self.k, ld=self.ld, side=self.csr, U=self.U, Z=self.Z, b_u=self.b_u,
@@ -1059,14 +1099,16 @@ class _Engine:
             model.history[key].extend(float(x) for x in h[:, j])
 
     # -------------------------------------------------------------- predict
-    def _compose_for(self, features):
-        """Z for `features` as passed to predict (scripts/als.py:568-572)."""
+    def _compose_for(self, features, features_of_fit: bool = False):
+        """Z for `features` as passed to predict (scripts/als.py:568-572): composed from whatever is passed.
+        `features_of_fit`: the caller vouches that these are the unchanged arrays of the fit (sweep.SweepDriver,
+        which owns them) - the fit's own Z = V + sum_f X_f W_f is then current and nothing is uploaded.  (Round 2
+        inferred that from object identity, which says nothing about the contents and can be recycled.)"""
         names = [f for f in features if f in self.W64]
         if not names:
             return self.V
-        if (self.iters_run > 0 and names == self.feat_names
-                and tuple((f, id(features[f])) for f in names) == getattr(self, "_feat_key", None)):
-            return self.Z                   # the very arrays of the fit: Z = V + sum_f X_f W_f is current
+        if features_of_fit and self.iters_run > 0 and names == self.feat_names:
+            return self.Z
         Xcat = np.concatenate([np.asarray(features[f], dtype=np.float32) for f in names], axis=1)
         Xp = np.zeros((self.n_pad, Xcat.shape[1]), dtype=np.float32)
         Xp[: self.n] = Xcat
@@ -1093,9 +1135,9 @@ class _Engine:
         is_ = torch.from_numpy(i.astype(np.int32)).to(self.dev)
         return self.predict_pairs(us, is_, features).cpu().numpy().astype(np.float64)
 
-    def predict_pairs(self, us: torch.Tensor, is_: torch.Tensor, features) -> torch.Tensor:
+    def predict_pairs(self, us: torch.Tensor, is_: torch.Tensor, features, features_of_fit: bool = False) -> torch.Tensor:
         """Predictions at (user, item) index tensors already on the device (int32); fp32 device tensor."""
-        Z = self._compose_for(features)
+        Z = self._compose_for(features, features_of_fit)
         out = torch.empty(us.numel(), dtype=torch.float32, device=self.dev)
         self.be.predict_at(k=self.k, ld=self.ld, us=us, is_=is_, U=self.U, Z=Z, b_u=self.b_u,
                            b_i=self.b_i, mu=self.mu, out=out)

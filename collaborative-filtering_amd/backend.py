@@ -24,13 +24,14 @@ def _p(t: Optional[torch.Tensor]):
 class HipBackend:
     name = "hip"
 
-    GRAM_MODES = {"f32": 0, "bf16x3": 1, "f64": 2}
+    GRAM_MODES = {"f32": 0, "f16x2": 1, "f64": 2}
+    COND_LIMIT = 10.0
 
-    def __init__(self, device: torch.device, gram: str = "bf16x3", solve_dtype: str = "float32"):
-        if gram not in ("f32", "bf16x3"):
-            raise ValueError("gram must be 'bf16x3' or 'f32'")
-        if solve_dtype not in ("float32", "float64"):
-            raise ValueError("solve_dtype must be 'float32' or 'float64'")
+    def __init__(self, device: torch.device, gram: str = "f16x2", solve_dtype: str = "auto"):
+        if gram not in ("f32", "f16x2"):
+            raise ValueError("gram must be 'f16x2' or 'f32'")
+        if solve_dtype not in ("auto", "float32", "float64"):
+            raise ValueError("solve_dtype must be 'auto', 'float32' or 'float64'")
         # solve_dtype="float64": Gram, Cholesky and substitutions of every row in fp64 (ALS_GRAM_F64); `gram` then
         # has no effect
         self.solve_dtype = solve_dtype
@@ -44,11 +45,20 @@ class HipBackend:
                                            device=device)
         self._stats_partials: Optional[torch.Tensor] = None
         self._spd_ws: Optional[torch.Tensor] = None
-        self._row_scratch: dict = {}       # k -> scratch of the two-waves-per-row kernel (als_row_solve_scratch_bytes)
-        # ALS_ROW_PAIR=1: k = 97 ... 128 on the two-waves-per-row kernel (row_pair.hip).  Measured slower than one
-        # wave per row on short rows and equal on long ones, so it is opt-in
-        self.row_pair = os.environ.get("ALS_ROW_PAIR", "0") == "1"
+        # operand scale of the f16x2 Gram ({S, 1 / S^2} of the gathered factor matrix + two working words that stay
+        # zero between calls: als_factor_scale); one per backend - calls on one stream run in order
+        self._fscale = torch.zeros(4, dtype=torch.float32, device=device)
         self.ablate = int(os.environ.get("ALS_ABLATE", "0"))   # phase ablation of als_row_solve (profiles/ablate.sh)
+        # solve_dtype="auto": rows whose condition estimate kappa = (max L_ii / min L_ii)^2 (from their own fp32
+        # factorisation; a LOWER bound of cond_2, typically within a factor of a few) exceeds COND_LIMIT are redone in
+        # fp64 by the same call, as are rows whose closed-form residual statistics cancel to fewer than three digits.
+        # Calibration (profiles/r03_cond_estimates.txt): cfg 4 rows have kappa <= 4.1, the lambda = 1e-2 fixture
+        # 14 ... 1300, lambda = 1e-4 10^3 ... 3 10^5; a row that stays fp32 has a relative error of about
+        # 3 kappa 3e-7 <= 1e-5.  ALS_COND_LIMIT overrides (experiments).
+        self.cond_limit = float(os.environ.get("ALS_COND_LIMIT", self.COND_LIMIT)) if solve_dtype == "auto" else 0.0
+        self._redo_count = torch.zeros(1, dtype=torch.int32, device=device)
+        self._redo_rows: dict = {}         # rows of the orientation -> int32 list buffer
+        self.cond_probe: Optional[torch.Tensor] = None     # diagnostics: float32 [nrows], receives every row's estimate
 
     # -- helpers -------------------------------------------------------------
     def _stream(self):
@@ -59,19 +69,24 @@ class HipBackend:
         if rc != 0:
             raise RuntimeError(f"{what} failed with status {rc} (see ALS_E_* in include/als_hip.h)")
 
-    def slot_bytes(self, k: int) -> int:
-        if self.gram_mode == self.GRAM_MODES["f64"]:
+    def slot_bytes(self, k: int, f64: bool = False) -> int:
+        """Bytes of one partial slot of a split row (fp64 calls keep an fp64 image per segment)."""
+        if f64 or self.gram_mode == self.GRAM_MODES["f64"]:
             return int(self.lib.als_partial_slot_bytes_f64(k))
         return int(self.lib.als_partial_slot_bytes(k))
 
     # -- K1 ------------------------------------------------------------------
     def row_solve(self, *, k, ld, side, F, zero_row, bias_self, bias_other, mu, lam, lam_row, lam_b,
                   lam_b_row, rhs_extra, diag_extra, X_out, bias_out, gram_out, factor_out,
-                  rhs_out, colsum_out, sumr_out, status, tasks, workspace, sumr2_out=None, stat_out=None):
+                  rhs_out, colsum_out, sumr_out, status, tasks, workspace, sumr2_out=None, stat_out=None,
+                  f64=False):
+        """`f64`: this call in fp64 whatever the backend's mode, by-product arrays (gram_out, factor_out, rhs_out,
+        colsum_out, sumr_out, sumr2_out) being DOUBLE tensors (the engine's fp64 V-step)."""
         p = _hip.RowSolveParams()
         p.k, p.ld, p.nrows, p.F_zero_row = k, ld, side.nrows, int(zero_row)
         p.reserved0 = self.ablate          # 0 in production; profiling builds of bench.py set it
-        p.gram_mode = self.gram_mode
+        p.gram_mode = self.GRAM_MODES["f64"] if f64 else self.gram_mode
+        p.byproducts_f64 = int(bool(f64))
         p.indptr, p.indices, p.vals = _p(side.indptr), _p(side.indices), _p(side.vals)
         p.F, p.bias_self, p.bias_other, p.mu = _p(F), _p(bias_self), _p(bias_other), _p(mu)
         p.lambda_scalar, p.lambda_row = float(lam), _p(lam_row)
@@ -85,23 +100,20 @@ class HipBackend:
         p.ndual_mid = int(getattr(tasks, "nmid", 0))
         p.long_rows, p.nlong = _p(tasks.long_rows), tasks.nlong
         p.workspace = _p(workspace)
-        p.scratch = _p(self._scratch_for(k))
+        p.F_scale, p.F_scale_ready = _p(self._fscale), 0
+        if self.cond_limit > 0.0 and not self.ablate and not f64:
+            if side.nrows not in self._redo_rows:
+                self._redo_rows[side.nrows] = torch.empty(max(side.nrows, 1), dtype=torch.int32, device=self.device)
+            p.cond_limit = self.cond_limit
+            p.redo_count, p.redo_rows = _p(self._redo_count), _p(self._redo_rows[side.nrows])
+            p.cond_out = _p(self.cond_probe) if (self.cond_probe is not None and self.cond_probe.numel() >= side.nrows) else None
         self._check(self.lib.als_row_solve(C.byref(p), self._stream()), "als_row_solve")
-
-    def _scratch_for(self, k: int) -> Optional[torch.Tensor]:
-        """Scratch of als_row_solve for k factors: one per backend, calls on one stream run in order."""
-        if not self.row_pair or self.ablate:
-            return None
-        if k not in self._row_scratch:
-            nbytes = int(self.lib.als_row_solve_scratch_bytes(k))
-            self._row_scratch[k] = (torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
-                                    if nbytes > 0 else None)
-        return self._row_scratch[k]
 
     # -- K2 ------------------------------------------------------------------
     def gs_level(self, *, k, ld, items, S_ptr, S_idx, S_val, alpha, factor, rhs, colsum, sumr,
-                 indptr, lam_b, lam_b_row, V, bias, sumr2=None, lambda_eff=None, stat_out=None):
+                 indptr, lam_b, lam_b_row, V, bias, sumr2=None, lambda_eff=None, stat_out=None, f64=False):
         p = _hip.GsSweepParams()
+        p.f64 = int(bool(f64))
         p.sumr2, p.lambda_eff, p.stat_out = _p(sumr2), _p(lambda_eff), _p(stat_out)
         p.k, p.ld = k, ld
         p.items, p.nitems = _p(items), items.numel()
@@ -120,6 +132,7 @@ class HipBackend:
         p.indptr, p.lambda_bias_scalar, p.lambda_bias_row = _p(kw["indptr"]), float(kw["lam_b"]), _p(kw["lam_b_row"])
         p.V, p.bias = _p(kw["V"]), _p(kw["bias"])
         p.sumr2, p.lambda_eff, p.stat_out = _p(kw.get("sumr2")), _p(kw.get("lambda_eff")), _p(kw.get("stat_out"))
+        p.f64 = int(bool(kw.get("f64", False)))
         return p
 
     def gs_dataflow(self, *, items, S_idx_wait, publish, err, nondep=None, **kw):
@@ -141,32 +154,36 @@ class HipBackend:
         p.indptr, p.lambda_bias_scalar, p.lambda_bias_row = _p(kw["indptr"]), float(kw["lam_b"]), _p(kw["lam_b_row"])
         p.V, p.bias = _p(kw["V"]), _p(kw["bias"])
         p.sumr2, p.lambda_eff, p.stat_out = _p(kw.get("sumr2")), _p(kw.get("lambda_eff")), _p(kw.get("stat_out"))
+        p.f64 = int(bool(kw.get("f64", False)))
         off = offsets.ctypes.data_as(C.c_void_p)
         self._check(self.lib.als_gs_sweep_levels(C.byref(p), off, len(offsets) - 1, self._stream()),
                     "als_gs_sweep_levels")
 
     # -- K3/K4 ---------------------------------------------------------------
     def w_item_vectors(self, *, k, ld, item_begin, item_end, gram, rhs, colsum, V, b_new, b_old, X, feat_off,
-                       W, H):
+                       W, H, f64=False):
+        """`f64`: gram / rhs / colsum / H are double tensors and W is the fp64 projection matrix [D, k]."""
         p = _hip.WParams()
+        p.f64 = int(bool(f64))
         p.k, p.ld, p.phase, p.nfeat = k, ld, 0, feat_off.numel() - 1
         p.item_begin, p.item_end = int(item_begin), int(item_end)
         p.gram, p.rhs, p.colsum, p.V, p.b_new, p.b_old = _p(gram), _p(rhs), _p(colsum), _p(V), _p(b_new), _p(b_old)
         p.D, p.X, p.feat_off, p.W, p.H, p.nrows_h = X.shape[1], _p(X), _p(feat_off), _p(W), _p(H), H.shape[1]
         self._check(self.lib.als_w_normal_equations(C.byref(p), self._stream()), "als_w_normal_equations(0)")
 
-    def w_accumulate(self, *, k, ld, item_begin, item_end, gram, X, H, feat_index, feat_col0, feat_d):
+    def w_accumulate(self, *, k, ld, item_begin, item_end, gram, X, H, feat_index, feat_col0, feat_d, f64=False):
         """(A [(d k)^2], B [d k]) fp64, storage order, for one feature over items [item_begin, item_end)."""
         npairs = feat_d * (feat_d + 1) // 2
         nit = max(int(item_end) - int(item_begin), 1)
         nchunks = max(1, min(512, 4096 // npairs, -(-nit // 64)))
         kb = ld // 16
-        f64 = torch.float64
-        partA = torch.empty(npairs * nchunks * (kb * (kb + 1) // 2) * 256, dtype=f64, device=self.device)
-        partB = torch.empty(feat_d * nchunks * ld, dtype=f64, device=self.device)
-        A = torch.empty(feat_d * k, feat_d * k, dtype=f64, device=self.device)
-        B = torch.empty(feat_d * k, dtype=f64, device=self.device)
+        dbl = torch.float64
+        partA = torch.empty(npairs * nchunks * (kb * (kb + 1) // 2) * 256, dtype=dbl, device=self.device)
+        partB = torch.empty(feat_d * nchunks * ld, dtype=dbl, device=self.device)
+        A = torch.empty(feat_d * k, feat_d * k, dtype=dbl, device=self.device)
+        B = torch.empty(feat_d * k, dtype=dbl, device=self.device)
         p = _hip.WParams()
+        p.f64 = int(bool(f64))
         p.k, p.ld, p.phase = k, ld, 1
         p.item_begin, p.item_end = int(item_begin), int(item_end)
         p.gram, p.D, p.X, p.H, p.nrows_h = _p(gram), X.shape[1], _p(X), _p(H), H.shape[1]
@@ -203,15 +220,16 @@ class HipBackend:
             "als_residual_stats")
 
     def item_stats(self, *, k, ld, item_begin, item_end, gram, rhs, colsum, sumr, sumr2, indptr, Z, b_new, b_old,
-                   stat_out):
-        """Per-item closed-form residual sums when Z != V (als_item_stats)."""
-        self._check(self.lib.als_item_stats(k, ld, int(item_begin), int(item_end), _p(gram), _p(rhs), _p(colsum),
-                                            _p(sumr), _p(sumr2), _p(indptr), _p(Z), _p(b_new), _p(b_old),
-                                            _p(stat_out), self._stream()), "als_item_stats")
+                   stat_out, f64=False):
+        """Per-item closed-form residual sums when Z != V (als_item_stats / als_item_stats_f64)."""
+        fn = self.lib.als_item_stats_f64 if f64 else self.lib.als_item_stats
+        self._check(fn(k, ld, int(item_begin), int(item_end), _p(gram), _p(rhs), _p(colsum),
+                       _p(sumr), _p(sumr2), _p(indptr), _p(Z), _p(b_new), _p(b_old),
+                       _p(stat_out), self._stream()), "als_item_stats")
 
     def sum_pairs(self, x: torch.Tensor, out: torch.Tensor):
         """out[0:2] = column sums of x viewed as [n, 2] (fp64, deterministic)."""
-        x = getattr(x, "t", x)              # a rank-local by-product array (als._RowShift): reduce what exists
+        x = getattr(x, "base", x)           # a rank-local by-product array (als._RowShift): reduce what exists
         if getattr(self, "_pair_partials", None) is None:
             self._pair_partials = torch.empty(2 * self._sumsq_partials.numel(), dtype=torch.float64, device=self.device)
         part = self._pair_partials

@@ -59,6 +59,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});    // row_bcast31 into rows 2, 3
     return readlane_f(v, 63);
 }
+// Maximum over the 64 lanes of NON-NEGATIVE floats (their bit patterns order like unsigned integers), result in
+// every lane: the DPP ladder of wave_sum with v_max_u32.
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    auto dpp = [](uint32_t x, auto ctrl, auto rows) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, decltype(ctrl)::value, decltype(rows)::value, 0xf, false);
+    };
+    using std::integral_constant;
+    uint32_t u = (uint32_t)__float_as_int(v);
+    u = max(u, dpp(u, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{}));
+    u = max(u, dpp(u, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{}));
+    u = max(u, dpp(u, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{}));
+    u = max(u, dpp(u, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{}));
+    u = max(u, dpp(u, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}));    // rows 0, 2 keep their own (bound_ctrl off: old value 0)
+    u = max(u, dpp(u, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}));
+    return __int_as_float(__builtin_amdgcn_readlane((int)u, 63));
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -117,10 +133,10 @@ struct KCfg {
     // a 2-way conflict on ds_write_b32 / ds_read_b32 hides behind the instruction's own issue cycles.)
     // waves per workgroup / minimum waves per SIMD asked of the register allocator
     static constexpr int WPW = (KB <= 4) ? 4 : (KB <= 6 ? 2 : 1);
-#ifndef ALS_MINW4
-#define ALS_MINW4 0
+#ifndef ALS_MINW_LE4
+#define ALS_MINW_LE4 3      // (tunable of development builds; 4 = 128 registers spills in K1)
 #endif
-    static constexpr int MINW = (KB <= 4) ? (ALS_MINW4 ? 4 : 3) : (KB <= 6 ? 2 : 1);
+    static constexpr int MINW = (KB <= 4) ? ALS_MINW_LE4 : (KB <= 6 ? 2 : 1);
     static constexpr int SLOT_ITEMS = NACC * 4 + 2 * KB + 2;  // per-lane floats of a partial
     // gather steps (4 ratings each) staged in registers at a time
     static constexpr int GS = (KB <= 8) ? 8 : 4;

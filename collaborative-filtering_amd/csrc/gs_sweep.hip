@@ -153,6 +153,107 @@ void k_gs_level(const als_gs_sweep_params P) {
 }
 
 // ---------------------------------------------------------------------------
+// The level kernel on FLOAT64 by-products (als_gs_sweep_params::f64: factor, rhs, colsum, sumr, sumr2 are doubles
+// written by als_row_solve with gram_mode ALS_GRAM_F64 and byproducts_f64): neighbour sum, both substitutions, bias
+// and statistics in fp64 - solve_dtype="float64" end to end (the reference's type, scripts/als.py:455-466).  The
+// factor streams from memory (one coalesced row per step); an accuracy path, not tuned.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+template <int KB>
+__global__ __launch_bounds__(64)
+void k_gs_level_f64(const als_gs_sweep_params P) {
+    using C = KCfg<KB>;
+    constexpr int KP = C::KP, NR = C::NR;
+    const int lane = threadIdx.x;
+    if ((int64_t)blockIdx.x >= P.nitems) return;
+    const int item = P.items[blockIdx.x];
+    const int64_t i64 = item;
+    const int64_t s0 = P.S_ptr[item], s1 = P.S_ptr[item + 1];
+    const double* M = (const double*)P.factor + i64 * KP * KP;
+    const double* rhs = (const double*)P.rhs + i64 * KP;
+    const double* colsum = (const double*)P.colsum + i64 * KP;
+    int ic[NR], col[NR];
+    double g[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        ic[rr] = min(lane + 64 * rr, KP - 1);
+        col[rr] = perm_to_col<KB>(ic[rr]);
+        g[rr] = 0.0;
+    }
+    for (int64_t t = s0; t < s1; ++t) {                     // S[i] @ V in index order (scripts/als.py:458)
+        const int sj = P.S_idx[t];
+        const double sv = (double)P.S_val[t];
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) g[rr] = fma(sv, (double)P.V[(int64_t)sj * P.ld + col[rr]], g[rr]);
+    }
+    double di[NR], rs[NR], rhs_i[NR], y[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        di[rr] = M[ic[rr] * KP + ic[rr]];
+        rhs_i[rr] = rhs[ic[rr]];
+        rs[rr] = (rhs_i[rr] + (double)P.alpha * g[rr]) * di[rr];
+    }
+    for (int j = 0; j < KP; ++j) {                          // L y = b (pre-scaled running vector)
+        double sel = rs[0];
+#pragma unroll
+        for (int rr = 1; rr < NR; ++rr) sel = ((j >> 6) == rr) ? rs[rr] : sel;
+        const double yj = readlane_f64(sel, j & 63);
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            const double cf = (lane + 64 * rr > j) ? M[j * KP + ic[rr]] * di[rr] : 0.0;
+            rs[rr] = fma(-cf, yj, rs[rr]);
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) { y[rr] = rs[rr]; rs[rr] *= di[rr]; }
+    for (int i = KP - 1; i >= 0; --i) {                     // L^T x = y
+        double sel = rs[0];
+#pragma unroll
+        for (int rr = 1; rr < NR; ++rr) sel = ((i >> 6) == rr) ? rs[rr] : sel;
+        const double xi = readlane_f64(sel, i & 63);
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            const double cf = (lane + 64 * rr < i) ? M[i * KP + ic[rr]] * di[rr] : 0.0;
+            rs[rr] = fma(-cf, xi, rs[rr]);
+        }
+    }
+    double dot = 0.0, xr = 0.0, yy = 0.0, xx = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr)
+        if (lane + 64 * rr < KP) {
+            const double x = rs[rr];
+            P.V[i64 * P.ld + col[rr]] = (float)x;
+            dot = fma(colsum[ic[rr]], x, dot); xr = fma(rhs_i[rr], x, xr);
+            yy = fma(y[rr], y[rr], yy); xx = fma(x, x, xx);
+        }
+    dot = wave_sum_d(dot);
+    const double nnz = (double)(P.indptr[item + 1] - P.indptr[item]);
+    const double lb = (double)(P.lambda_bias_row ? P.lambda_bias_row[item] : P.lambda_bias_scalar);
+    const double sumr = ((const double*)P.sumr)[item];
+    const double bnew = (sumr - dot) / (nnz + lb + 1e-10);
+    const double bold = (double)P.bias[item];
+    __builtin_amdgcn_sched_barrier(0);
+    if (lane == 0) P.bias[item] = (float)bnew;
+    if (P.stat_out) {
+        xr = wave_sum_d(xr); yy = wave_sum_d(yy); xx = wave_sum_d(xx);
+        if (lane == 0) {
+            const double sumr2 = ((const double*)P.sumr2)[item];
+            const double s1v = sumr - nnz * bnew;
+            const double s2v = sumr2 - 2.0 * bnew * sumr + nnz * bnew * bnew;
+            const double cross = xr + (bold - bnew) * dot;
+            const double quad = yy - (double)P.lambda_eff[item] * xx;
+            P.stat_out[2 * i64] = (float)(s1v - dot);
+            P.stat_out[2 * i64 + 1] = (float)(s2v - 2.0 * cross + quad);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K2': the whole sweep as ONE persistent, synchronisation-free launch.
 //
 // Items are listed in (level, id) order and dealt round-robin to the `nwaves` waves of the launch; each wave
@@ -539,6 +640,10 @@ template <int KB>
 int launch_gs(const als_gs_sweep_params* p, hipStream_t st) {
     constexpr int WPW = GsCfg<KB>::WPW;
     if (p->nitems <= 0) return 0;
+    if (p->f64) {
+        hipLaunchKernelGGL(k_gs_level_f64<KB>, dim3((unsigned)p->nitems), dim3(64), 0, st, *p);
+        return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
+    }
     const unsigned grid = (unsigned)((p->nitems + WPW - 1) / WPW);
     hipLaunchKernelGGL(k_gs_level<KB>, dim3(grid), dim3(64 * WPW), 0, st, *p);
     return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
@@ -559,7 +664,7 @@ void k_fill_words(uint32_t* __restrict__ dst, int64_t nwords, uint32_t word) {
 
 extern "C" int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t* S_idx_wait, float* publish,
                                      int64_t nrows, float* nondep, int32_t* err, void* stream) {
-    if (!p || !S_idx_wait || !publish || !err || nrows < 0) return ALS_E_BADARG;
+    if (!p || !S_idx_wait || !publish || !err || nrows < 0 || p->f64) return ALS_E_BADARG;   // (fp64 by-products: level launches)
     const int ld = als_padded_k(p->k);
     if (ld < 0) return ALS_E_BADK;
     if (p->ld != ld || p->nitems < 0 || !p->S_ptr || !p->S_val || !p->factor || !p->rhs || !p->colsum ||
@@ -613,7 +718,7 @@ extern "C" int als_gs_sweep(const als_gs_sweep_params* p, void* stream) {
         !p->sumr || !p->indptr || !p->V || !p->bias)
         return ALS_E_BADARG;
     if (p->nitems > 0 && !p->items) return ALS_E_BADARG;
-    if (p->stat_out && (!p->sumr2 || !p->lambda_eff || ld > 64)) return ALS_E_BADARG;   // fused stats: k <= 64
+    if (p->stat_out && (!p->sumr2 || !p->lambda_eff || (ld > 64 && !p->f64))) return ALS_E_BADARG;   // fused stats: k <= 64 (fp32 form)
     hipStream_t st = (hipStream_t)stream;
     switch (ld / 16) {
         case 1: return launch_gs<1>(p, st);

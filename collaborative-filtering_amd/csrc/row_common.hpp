@@ -1,6 +1,5 @@
-// Pieces of the row-solve kernels shared by row_solve.hip (one wave per row) and row_pair.hip (two waves per
-// row at k = 112 / 128): the exact 3-way bf16 split, the per-wave Cholesky state, the DPP panel update and the
-// transposed solve from the L image in LDS.
+// Pieces of the row-solve kernels (row_solve.hip): the fp16 operand split, the per-wave Cholesky state, the DPP
+// panel update and the transposed solve from the L image in LDS.
 #pragma once
 #include <type_traits>
 #include "als_device.hpp"
@@ -9,27 +8,38 @@ namespace {
 
 __host__ __device__ constexpr int blk_idx(int I, int K) { return I * (I + 1) / 2 + K; }
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ int pack_hi16(float hi_src, float lo_src) {     // {hi_src[31:16], lo_src[31:16]}
-    return __builtin_amdgcn_perm(__float_as_int(hi_src), __float_as_int(lo_src), 0x07060302);
+// 2-way fp16 split of two floats, fp32-equivalent (see process_chunk_f16x2): with S an exact power-of-two scale
+// that puts the largest |x| of the whole factor matrix just below 2^15 (als_factor_scale),
+//     x S = h + l + e,   h = fp16(x S),  l = fp16(x S - h)  (both round-to-nearest),  |e| <= 2^-23 |x S|:
+// h carries 11 significant bits, the remainder is exact in fp32 and at most half an ulp of h, so its own 11 bits
+// (plus its sign) reach the 2^-23 level - the fp32 representation error is 2^-24.  The scale keeps l out of the
+// fp16 subnormal range for every element within 2^-14 of the matrix maximum (smaller elements lose relative,
+// not absolute, precision: below 2^-38 of the largest Gram term).  6 VALU per pair: 2 v_mul, 2 v_cvt_pk_f16_f32,
+// 2 v_fma_mix_f32 (the bf16 3-way split by truncation of rounds 1-2 took 11 and twice the matrix instructions).
+__device__ __forceinline__ void split2(float x0, float x1, float S, int& H, int& L) {
+    const float y0 = x0 * S, y1 = x1 * S;
+    const h16x2 h = __builtin_convertvector(f32x2{y0, y1}, h16x2);
+    const float d0 = fmaf((float)h[0], -1.0f, y0), d1 = fmaf((float)h[1], -1.0f, y1);        // exact
+    const h16x2 l = __builtin_convertvector(f32x2{d0, d1}, h16x2);
+    H = __builtin_bit_cast(int, h);
+    L = __builtin_bit_cast(int, l);
 }
 
-// exact 3-way bf16 split of two floats (see process_chunk_bf16x3): packed high halves of x, of r = x - h and of
-// l = r - m.  (v_dot2c_f32_bf16 with a (-1, 0) constant on the packed word would form a remainder in one
-// instruction instead of v_and + v_sub; on gfx950 it did NOT reproduce the remainders bit for bit and issues at
-// half rate with three waves per SIMD - profiles/ubench/split_dot2c.hip, profiles/r02_ubench_split_dot2c.txt.)
-__device__ __forceinline__ void split3(float x0, float x1, int& H, int& M, int& L) {
-    H = pack_hi16(x1, x0);
-    const float h0 = __int_as_float(__float_as_int(x0) & 0xFFFF0000);
-    const float h1 = __int_as_float(__float_as_int(x1) & 0xFFFF0000);
-    const float r0 = x0 - h0, r1 = x1 - h1;                       // exact
-    M = pack_hi16(r1, r0);
-    const float m0 = __int_as_float(__float_as_int(r0) & 0xFFFF0000);
-    const float m1 = __int_as_float(__float_as_int(r1) & 0xFFFF0000);
-    const float l0 = r0 - m0, l1 = r1 - m1;                       // exact, <= 8 significant bits
-    L = pack_hi16(l1, l0);
+// Between the last v_mfma_f32_16x16x32_f16 of a Gram loop and the first vector instruction that reads the
+// accumulators.  hipcc (ROCm 7.2) pads this matrix-result -> vector-read hazard (an 8-pass matrix instruction: 11
+// wait states) too little on one path of k_row_dual - when the branch around the optional lambda_row load is taken
+// the unscaling v_pk_mul_f32 follows the last MFMAs within a handful of instructions: a few rows in 10^5 came out as
+// garbage / NaN, differently from run to run (cfg5-small, rows of 33 ... 48 ratings; found with
+// profiles/debug/dual_probe.py, round 3).  The wait states are therefore spelled out - 20 idle cycles per row -
+// and tests/test_isa_hazards_cpu.py checks the distance in the built code object.
+__device__ __forceinline__ void mfma_results_settle() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // ---------------------------------------------------------------------------

@@ -26,8 +26,6 @@
 #include "als_hip.h"
 #include "row_common.hpp"
 
-int als_row_pair_dispatch(const als_row_solve_params* p, hipStream_t st);          // row_pair.hip
-
 namespace {
 
 template <int KB>
@@ -91,87 +89,26 @@ __device__ __forceinline__ void process_chunk(RowAcc<KB>& A, int off_l, float r_
 }
 
 // ---------------------------------------------------------------------------
-// Same 64 ratings on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16), fp32-equivalent.
-// Every gathered float is split EXACTLY into three bf16 terms by truncation,
-//     x = h + m + l,   h = top 16 bits of x,  m = top 16 bits of (x - h),  l = x - h - m
-// (l has at most 8 significant bits left, so it is representable), and the Gram block is
-// the sum of the six cross products hh + hm + mh + mm + hl + lh accumulated in fp32; the
-// three dropped ones (ml, lm, ll) are <= 2^-24 relative, i.e. at the fp32 rounding level.
-// bf16 MFMA runs beside the VALU (f32 MFMA does not - DESIGN.md section 4), the splitting
-// arithmetic is the VALU's share.  Lane (c,q) now takes ratings 8q..8q+7 of a 32-rating
-// group: the 8 values it loads per block are exactly its 8 k-elements of the A/B operand.
+// Same 64 ratings on the fp16 matrix cores (v_mfma_f32_16x16x32_f16), fp32-equivalent.
+// Every gathered float is scaled by S (an exact power of two, one per factor matrix: als_factor_scale) and split
+// into two fp16 terms by rounding to nearest,
+//     x S = h + l + e,   h = fp16(x S),  l = fp16(x S - h),  |e| <= 2^-23 |x S|         (split2, row_common.hpp)
+// and a Gram block is the fp32-accumulated sum of the three cross products hh + hl + lh (all exact in fp32:
+// 11 x 11 bits); the dropped ll is <= 2^-24 relative.  The accumulators hold S^2 G and are unscaled once per
+// row (finish_row).  Measured against fp64 (profiles/ubench/gram_f16x2.hip, profiles/r03_ubench_gram_f16x2.txt):
+// the same error as the exact 3-way bf16 split of rounds 1-2 (six products per block) and as the f32 MFMA - at
+// half the matrix instructions and 6 instead of 11 VALU per pair of elements (856 instead of 1522 cycles per
+// 32-rating group and SIMD).  The 16-bit matrix cores run beside the VALU (f32 MFMA does not - DESIGN.md
+// section 4).  Lane (c,q) takes ratings 8q..8q+7 of a 32-rating group: the 8 values it loads per block are
+// exactly its 8 k-elements of the A/B operand.
 // ---------------------------------------------------------------------------
 
-typedef short bf16x4 __attribute__((ext_vector_type(4)));
-typedef int i32x2 __attribute__((ext_vector_type(2)));
-
-// Last group of a row with at most 16 ratings left (ALS_TAIL16): the same six products on
-// v_mfma_f32_16x16x16_bf16 - lane (c, q) takes ratings t0 + 4q .. 4q+3 - instead of a 32-rating group that is
-// more than half padding.  (As the only group size this form measured slower, profiles/r02_ab_g16.txt: twice the
-// MFMA instructions per rating; as the tail it replaces a whole group by half of one.)
-// MEASURED AND NOT ADOPTED (profiles/r02_ab_tail16.txt, cfg 4): U-step 6.90 vs 6.88 ... 6.98 ms, V-step 4.63 vs
-// 4.47 ms - the second code path costs 12 spilled registers at the 168-register cap and what it saves (a quarter
-// of a group per row on average) does not show.
-#ifndef ALS_TAIL16
-#define ALS_TAIL16 0
-#endif
-template <int KB>
-__device__ __forceinline__ void process_tail16_bf16x3(RowAcc<KB>& A, int off_l, float r_l, int t0,
-                                                      const float* __restrict__ Fc, int q) {
-    int off_t[4];
-    float r_t[4];
-    float f[4][KB];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        off_t[j] = bperm_i(off_l, t0 + 4 * q + j);
-        r_t[j] = bperm_f(r_l, t0 + 4 * q + j);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) load_frow<KB>(Fc + (uint32_t)off_t[j], f[j]);
-    i32x2 H[KB], M[KB], L[KB];
-#pragma unroll
-    for (int b = 0; b < KB; ++b) {
-#pragma unroll
-        for (int j = 0; j < 4; j += 2) {
-            const float x0 = f[j][b], x1 = f[j + 1][b];
-            A.rhs[b] = fmaf(x0, r_t[j], A.rhs[b]);
-            A.rhs[b] = fmaf(x1, r_t[j + 1], A.rhs[b]);
-            A.cs[b] += x0 + x1;
-            int hw, mw, lw;
-            split3(x0, x1, hw, mw, lw);
-            H[b][j >> 1] = hw; M[b][j >> 1] = mw; L[b][j >> 1] = lw;
-        }
-    }
-#pragma unroll
-    for (int bi = 0; bi < KB; ++bi)
-#pragma unroll
-        for (int bj = 0; bj <= bi; ++bj) {
-            f32x4 acc = A.acc[blk_idx(bi, bj)];
-            const bf16x4 hi = __builtin_bit_cast(bf16x4, H[bi]), hj = __builtin_bit_cast(bf16x4, H[bj]);
-            const bf16x4 mi = __builtin_bit_cast(bf16x4, M[bi]), mj = __builtin_bit_cast(bf16x4, M[bj]);
-            const bf16x4 li = __builtin_bit_cast(bf16x4, L[bi]), lj = __builtin_bit_cast(bf16x4, L[bj]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(li, hj, acc, 0, 0, 0);     // smallest terms first
-            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi, lj, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(mi, mj, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(mi, hj, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi, mj, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi, hj, acc, 0, 0, 0);
-            A.acc[blk_idx(bi, bj)] = acc;
-        }
-}
-
 template <int KB, bool FULL>
-__device__ __forceinline__ void process_chunk_bf16x3(RowAcc<KB>& A, int off_l, float r_l, int nvalid,
-                                                     const float* __restrict__ Fc, int q) {
+__device__ __forceinline__ void process_chunk_f16x2(RowAcc<KB>& A, int off_l, float r_l, int nvalid,
+                                                    const float* __restrict__ Fc, int q, float S) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         if (!FULL && 32 * g >= nvalid) break;
-#if ALS_TAIL16
-        if (!FULL && nvalid - 32 * g <= 16) {
-            process_tail16_bf16x3<KB>(A, off_l, r_l, 32 * g, Fc, q);
-            break;
-        }
-#endif
         int off_t[8];
         float r_t[8];
         float f[8][KB];
@@ -182,7 +119,7 @@ __device__ __forceinline__ void process_chunk_bf16x3(RowAcc<KB>& A, int off_l, f
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) load_frow<KB>(Fc + (uint32_t)off_t[j], f[j]);
-        i32x4 H[KB], M[KB], L[KB];
+        i32x4 H[KB], L[KB];
 #pragma unroll
         for (int b = 0; b < KB; ++b) {
 #pragma unroll
@@ -191,9 +128,9 @@ __device__ __forceinline__ void process_chunk_bf16x3(RowAcc<KB>& A, int off_l, f
                 A.rhs[b] = fmaf(x0, r_t[j], A.rhs[b]);
                 A.rhs[b] = fmaf(x1, r_t[j + 1], A.rhs[b]);
                 A.cs[b] += x0 + x1;
-                int hw, mw, lw;
-                split3(x0, x1, hw, mw, lw);
-                H[b][j >> 1] = hw; M[b][j >> 1] = mw; L[b][j >> 1] = lw;
+                int hw, lw;
+                split2(x0, x1, S, hw, lw);
+                H[b][j >> 1] = hw; L[b][j >> 1] = lw;
             }
         }
 #pragma unroll
@@ -201,179 +138,19 @@ __device__ __forceinline__ void process_chunk_bf16x3(RowAcc<KB>& A, int off_l, f
 #pragma unroll
             for (int bj = 0; bj <= bi; ++bj) {
                 f32x4 acc = A.acc[blk_idx(bi, bj)];
-                const bf16x8 hi = __builtin_bit_cast(bf16x8, H[bi]), hj = __builtin_bit_cast(bf16x8, H[bj]);
-                const bf16x8 mi = __builtin_bit_cast(bf16x8, M[bi]), mj = __builtin_bit_cast(bf16x8, M[bj]);
-                const bf16x8 li = __builtin_bit_cast(bf16x8, L[bi]), lj = __builtin_bit_cast(bf16x8, L[bj]);
+                const h16x8 hi = __builtin_bit_cast(h16x8, H[bi]), hj = __builtin_bit_cast(h16x8, H[bj]);
+                const h16x8 li = __builtin_bit_cast(h16x8, L[bi]), lj = __builtin_bit_cast(h16x8, L[bj]);
                 // smallest terms first
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(li, hj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, lj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mi, mj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mi, hj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, mj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, hj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(li, hj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, lj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, hj, acc, 0, 0, 0);
                 A.acc[blk_idx(bi, bj)] = acc;
             }
     }
 }
 
-// F^T r and F^T 1 on the matrix cores as well (ALS_RHS_MFMA): one more MFMA chain per column block whose row
-// operand is "r" in rows 0..7 and "1" in rows 8..15 - lane (c, q) supplies row c, so lanes c < 8 hand in the split
-// residuals of ratings 8q .. 8q+7 and lanes c >= 8 the constant 1 (bf16 1.0 in the high plane, zeros in the other
-// two).  Output block b: rows 0..7 (lanes q < 2) all hold (F^T r)[16b + c], rows 8..15 (q >= 2) hold (F^T 1)[16b + c];
-// the same six-product scheme as the Gram, so F^T 1 is the exact fp32-accumulated sum h + m + l.  This takes the
-// 2 VALU operations per gathered element of the FMA form off the VALU (64 of ~300 instructions of a group at k = 64).
-// MEASURED AND NOT ADOPTED (profiles/r02_ab_rhs_mfma.txt, cfg 4): U-step 7.9 instead of 6.5 ms, V-step 5.7 instead of
-// 4.45 ms - 84 instead of 60 matrix instructions per group and 29 spilled registers at the 168-register cap cost
-// more than the 64 vector instructions save; results agree (train RMSE 0.419939242 vs 0.419939198).  Kept behind
-// the switch because the pre-split-planes idea would need it.
-// rp*: the residual of rating t, split exactly into three bf16 terms and packed with its neighbour's by lane t
-// (even t: {r[t+1] : r[t]}; odd t: the constant row) - formed once per 64-rating chunk, fetched with ds_bpermute.
-#ifndef ALS_RHS_MFMA
-#define ALS_RHS_MFMA 0
-#endif
-
-__device__ __forceinline__ void pack_residual_planes(float r_l, int lane, int& rph, int& rpm, int& rpl) {
-    auto nb = [](int x) {       // the value of lane t ^ 1
-        return __builtin_amdgcn_update_dpp(0, x, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
-    };
-    const int h = __float_as_int(r_l) & 0xFFFF0000;
-    const float r1 = r_l - __int_as_float(h);                   // exact
-    const int m = __float_as_int(r1) & 0xFFFF0000;
-    const int l = __float_as_int(r1 - __int_as_float(m));      // exact, <= 8 significant bits
-    // (the cross-lane reads happen in ALL lanes, before the select: inside a conditional the odd lanes would be
-    // masked off and the even ones would read zeros from them)
-    const int ph = __builtin_amdgcn_perm(nb(h), h, 0x07060302);
-    const int pm = __builtin_amdgcn_perm(nb(m), m, 0x07060302);
-    const int pl = __builtin_amdgcn_perm(nb(l), l, 0x07060302);
-    const bool odd = lane & 1;
-    rph = odd ? 0x3F803F80 : ph;
-    rpm = odd ? 0 : pm;
-    rpl = odd ? 0 : pl;
-}
-
-template <int KB, bool FULL>
-__device__ __forceinline__ void process_chunk_bf16x3_rm(RowAcc<KB>& A, f32x4 (&racc)[KB], int off_l, int rph, int rpm,
-                                                        int rpl, int nvalid, const float* __restrict__ Fc, int q,
-                                                        int c) {
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        if (!FULL && 32 * g >= nvalid) break;
-        int off_t[8];
-        float f[8][KB];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) off_t[j] = bperm_i(off_l, 32 * g + 8 * q + j);
-        i32x4 RH, RM, RL;
-        const int rsel = 32 * g + 8 * q + (c >= 8 ? 1 : 0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            RH[e] = bperm_i(rph, rsel + 2 * e);
-            RM[e] = bperm_i(rpm, rsel + 2 * e);
-            RL[e] = bperm_i(rpl, rsel + 2 * e);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) load_frow<KB>(Fc + (uint32_t)off_t[j], f[j]);
-        i32x4 H[KB], M[KB], L[KB];
-#pragma unroll
-        for (int b = 0; b < KB; ++b) {
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                int hw, mw, lw;
-                split3(f[j][b], f[j + 1][b], hw, mw, lw);
-                H[b][j >> 1] = hw; M[b][j >> 1] = mw; L[b][j >> 1] = lw;
-            }
-        }
-        const bf16x8 rh = __builtin_bit_cast(bf16x8, RH), rm = __builtin_bit_cast(bf16x8, RM),
-                     rl = __builtin_bit_cast(bf16x8, RL);
-#pragma unroll
-        for (int bi = 0; bi < KB; ++bi) {
-            const bf16x8 hi = __builtin_bit_cast(bf16x8, H[bi]), mi = __builtin_bit_cast(bf16x8, M[bi]),
-                         li = __builtin_bit_cast(bf16x8, L[bi]);
-            {
-                f32x4 acc = racc[bi];                    // smallest terms first, as the Gram blocks
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl, hi, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh, li, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rm, mi, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rm, hi, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh, mi, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh, hi, acc, 0, 0, 0);
-                racc[bi] = acc;
-            }
-#pragma unroll
-            for (int bj = 0; bj <= bi; ++bj) {
-                f32x4 acc = A.acc[blk_idx(bi, bj)];
-                const bf16x8 hj = __builtin_bit_cast(bf16x8, H[bj]), mj = __builtin_bit_cast(bf16x8, M[bj]),
-                             lj = __builtin_bit_cast(bf16x8, L[bj]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(li, hj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, lj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mi, mj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mi, hj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, mj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, hj, acc, 0, 0, 0);
-                A.acc[blk_idx(bi, bj)] = acc;
-            }
-        }
-    }
-}
-
-// The same Gram in groups of 16 ratings on v_mfma_f32_16x16x16_bf16 (4 k-elements per lane): lane (c,q) takes
-// ratings 4q .. 4q+3 of a 16-rating group.  Half the operand and staging registers of the 32-rating form
-// (H / M / L: 24 instead of 48, gathered rows: 4 x KB instead of 8 x KB), twice the MFMA instructions.
-#ifndef ALS_GRAM_G16
-#define ALS_GRAM_G16 0
-#endif
-
-template <int KB, bool FULL>
-__device__ __forceinline__ void process_chunk_bf16x3_g16(RowAcc<KB>& A, int off_l, float r_l, int nvalid,
-                                                         const float* __restrict__ Fc, int q) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if (!FULL && 16 * g >= nvalid) break;
-        int off_t[4];
-        float r_t[4];
-        float f[4][KB];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            off_t[j] = bperm_i(off_l, 16 * g + 4 * q + j);
-            r_t[j] = bperm_f(r_l, 16 * g + 4 * q + j);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) load_frow<KB>(Fc + (uint32_t)off_t[j], f[j]);
-        i32x2 H[KB], M[KB], L[KB];
-#pragma unroll
-        for (int b = 0; b < KB; ++b) {
-#pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                const float x0 = f[j][b], x1 = f[j + 1][b];
-                A.rhs[b] = fmaf(x0, r_t[j], A.rhs[b]);
-                A.rhs[b] = fmaf(x1, r_t[j + 1], A.rhs[b]);
-                A.cs[b] += x0 + x1;
-                int hw, mw, lw;
-                split3(x0, x1, hw, mw, lw);
-                H[b][j >> 1] = hw; M[b][j >> 1] = mw; L[b][j >> 1] = lw;
-            }
-        }
-#pragma unroll
-        for (int bi = 0; bi < KB; ++bi)
-#pragma unroll
-            for (int bj = 0; bj <= bi; ++bj) {
-                f32x4 acc = A.acc[blk_idx(bi, bj)];
-                const bf16x4 hi = __builtin_bit_cast(bf16x4, H[bi]), hj = __builtin_bit_cast(bf16x4, H[bj]);
-                const bf16x4 mi = __builtin_bit_cast(bf16x4, M[bi]), mj = __builtin_bit_cast(bf16x4, M[bj]);
-                const bf16x4 li = __builtin_bit_cast(bf16x4, L[bi]), lj = __builtin_bit_cast(bf16x4, L[bj]);
-                // smallest terms first
-                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(li, hj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi, lj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(mi, mj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(mi, hj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi, mj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hi, hj, acc, 0, 0, 0);
-                A.acc[blk_idx(bi, bj)] = acc;
-            }
-    }
-}
-
-// Long rows in bf16x3 mode: the bf16 MFMA's internal accumulation error grows linearly with the
-// number of accumulated groups (measured 1e-5 relative at 4000 ratings vs 3e-6 for f32 MFMA), so
+// Long rows in f16x2 mode: the 16-bit MFMA's internal accumulation error grows linearly with the
+// number of accumulated groups (measured with the bf16 form of rounds 1-2: 1e-5 relative at 4000 ratings), so
 // every FLUSH_GROUPS*32 ratings the accumulators are added (fp32, round-to-nearest) into totals
 // kept in the wave's LDS region - idle during the Gram phase and exactly NACC*256 floats - and
 // restarted from zero.
@@ -404,16 +181,10 @@ __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __
                                                 const float* __restrict__ valp, int len,
                                                 const float* __restrict__ F, int ld, int zero_row,
                                                 const float* __restrict__ bias_other, float mu,
-                                                float bself, int lane, float* __restrict__ Ls) {
+                                                float bself, int lane, float* __restrict__ Ls, float S) {
     const int c = lane & 15, q = lane >> 4;
     const float* Fc = F + KB * c;
     int nflush = 0;
-#if ALS_RHS_MFMA && !ALS_GRAM_G16
-    f32x4 racc[KB];
-    float rtot[KB];
-#pragma unroll
-    for (int b = 0; b < KB; ++b) { racc[b] = f32x4{0.f, 0.f, 0.f, 0.f}; rtot[b] = 0.f; }
-#endif
     // software pipeline over 64-rating chunks: indices two chunks ahead,
     // value + opposite-side bias one chunk ahead of the factor-row gathers
     // indices / values are read once: non-temporal, so that they do not push the gathered factor rows (244 MiB of
@@ -442,46 +213,20 @@ __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __
             if (nvalid == 64) process_chunk<KB, true>(A, off0, r0, 64, Fc, q);
             else              process_chunk<KB, false>(A, off0, r0, nvalid, Fc, q);
         } else {
-#if ALS_GRAM_G16
-            if (nvalid == 64) process_chunk_bf16x3_g16<KB, true>(A, off0, r0, 64, Fc, q);
-            else              process_chunk_bf16x3_g16<KB, false>(A, off0, r0, nvalid, Fc, q);
-#elif ALS_RHS_MFMA
-            int rph, rpm, rpl;
-            pack_residual_planes(r0, lane, rph, rpm, rpl);
-            if (nvalid == 64) process_chunk_bf16x3_rm<KB, true>(A, racc, off0, rph, rpm, rpl, 64, Fc, q, c);
-            else              process_chunk_bf16x3_rm<KB, false>(A, racc, off0, rph, rpm, rpl, nvalid, Fc, q, c);
-#else
-            if (nvalid == 64) process_chunk_bf16x3<KB, true>(A, off0, r0, 64, Fc, q);
-            else              process_chunk_bf16x3<KB, false>(A, off0, r0, nvalid, Fc, q);
-#endif
+            if (nvalid == 64) process_chunk_f16x2<KB, true>(A, off0, r0, 64, Fc, q, S);
+            else              process_chunk_f16x2<KB, false>(A, off0, r0, nvalid, Fc, q, S);
             if (((base >> 6) + 1) % (FLUSH_GROUPS / 2) == 0 && base + 64 < len) {
+                mfma_results_settle();
                 flush_acc<KB>(A, Ls, lane, nflush == 0);
                 ++nflush;
-#if ALS_RHS_MFMA && !ALS_GRAM_G16
-#pragma unroll
-                for (int b = 0; b < KB; ++b) { rtot[b] += racc[b][0]; racc[b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#endif
             }
         }
     }
+    if (MODE != 0) mfma_results_settle();         // whoever reads the accumulators next (totals, partial slot, finish_row)
     if (MODE != 0 && nflush > 0) {
         unflush_acc<KB>(A, Ls, lane);
         wave_lds_sync();
     }
-#if ALS_RHS_MFMA && !ALS_GRAM_G16
-    if (MODE != 0) {
-        // every register of racc[b] holds (F^T r)[16b + c] in the lanes q < 2 and (F^T 1)[16b + c] in the lanes
-        // q >= 2; the row's tail sums the four q groups of A.rhs / A.cs (per-lane partials of the FMA form, also the
-        // format of the split-row slots), so the totals go to the q = 0 lanes and zeros to the others
-#pragma unroll
-        for (int b = 0; b < KB; ++b) {
-            const float tot = rtot[b] + racc[b][0];
-            const float fr = bperm_f(tot, c), f1 = bperm_f(tot, 32 + c);
-            A.rhs[b] = (q == 0) ? fr : 0.f;
-            A.cs[b] = (q == 0) ? f1 : 0.f;
-        }
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -636,6 +381,36 @@ __device__ __forceinline__ void chol_panels(RowAcc<KB>& A, Chol<KB>& S, float* _
 }
 
 // ---------------------------------------------------------------------------
+// Conditioning-driven precision (als_row_solve_params::cond_limit).  After the fp32 factorisation the lanes hold
+// 1 / L_ii; kappa = (max L_ii / min L_ii)^2 is a lower bound of cond_2(A) (L_ii^2 are Schur-complement diagonals:
+// max_i L_ii^2 <= lambda_max, min_i L_ii^2 >= lambda_min) and within a small factor of it for the matrices met here
+// (G + lambda I with rank-deficient or low-rank G: the last pivots sit at ~lambda).  The fp32 rounding of the Gram
+// (~3e-7 |G|) reaches the solution amplified by cond(A); a row whose kappa exceeds the limit - or whose fp32
+// factorisation broke down - is handed to the fp64 kernel instead of being finished here.  14 + 3 vector
+// instructions per row.  Returns true when the row is to be redone (nothing of it may be stored then).
+// ---------------------------------------------------------------------------
+template <int KB>
+__device__ __forceinline__ bool row_needs_f64(const Chol<KB>& S, const als_row_solve_params& P, int row, bool spd,
+                                              int lane) {
+    float dmx = 0.f, dmn = 0.f;          // max of 1 / L_ii and of L_ii over the lane's rows
+#pragma unroll
+    for (int rr = 0; rr < KCfg<KB>::NR; ++rr) {
+        const bool in = lane + 64 * rr < KCfg<KB>::KP;
+        const float d = in ? S.di[rr] : 0.f;
+        dmx = fmaxf(dmx, d);
+        dmn = fmaxf(dmn, in ? __builtin_amdgcn_rcpf(d) : 0.f);
+    }
+    dmx = wave_max_nonneg(fmaxf(dmx, 0.f));
+    dmn = wave_max_nonneg(fmaxf(dmn, 0.f));
+    const float r = dmx * dmn;
+    const float kappa = spd ? r * r : __builtin_inff();
+    if (P.cond_out && lane == 0) P.cond_out[row] = kappa;
+    const bool redo = !(kappa <= P.cond_limit);
+    if (redo && lane == 0) P.redo_rows[atomicAdd(P.redo_count, 1)] = row;
+    return redo;
+}
+
+// ---------------------------------------------------------------------------
 // tail: reduce, regularise, factorise, solve / emit factor
 // ---------------------------------------------------------------------------
 template <int KB>
@@ -645,6 +420,12 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
     constexpr int KP = C::KP, NR = C::NR;
     const int c = lane & 15, q = lane >> 4;
     const int64_t r64 = row;
+
+    if (P.gram_mode == ALS_GRAM_F16X2) {        // the accumulators hold S^2 G (exact power of two)
+        const float un = P.F_scale[1];
+#pragma unroll
+        for (int a = 0; a < C::NACC; ++a) A.acc[a] *= un;
+    }
 
     // cross-lane reductions: rhs / colsum over the four q groups, sumr over the wave
 #pragma unroll
@@ -709,7 +490,10 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
 
     if (P.factor_out) {
         chol_panels<KB, 0, false>(A, S, Ls, lane);
-        if (!chol_spd<KB>(S, lane) && lane == 0) atomicMax(P.status, row + 1);
+        const bool spd = chol_spd<KB>(S, lane);
+        if (P.cond_limit > 0.f) {
+            if (row_needs_f64<KB>(S, P, row, spd, lane)) return;
+        } else if (!spd && lane == 0) atomicMax(P.status, row + 1);
         // symmetric completion of L with 1/L_ii on the diagonal, perm space:
         // M[p][i] = L[i][p] (p < i), L[p][i] (p > i)
         float* M = P.factor_out + r64 * KP * KP;
@@ -742,7 +526,10 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
     }
     if (!(P.reserved0 & 2)) {
         chol_panels<KB, 0, true>(A, S, Ls, lane);
-        if (!chol_spd<KB>(S, lane) && lane == 0) atomicMax(P.status, row + 1);
+        const bool spd = chol_spd<KB>(S, lane);
+        if (P.cond_limit > 0.f) {
+            if (row_needs_f64<KB>(S, P, row, spd, lane)) return;
+        } else if (!spd && lane == 0) atomicMax(P.status, row + 1);
     }
     float x[NR];
     if (!(P.reserved0 & 4)) backward_solve<KB>(Ls, S, x, lane);
@@ -755,7 +542,6 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
         if (lane + 64 * rr < KP) {
-            P.X_out[r64 * P.ld + colrow[rr]] = x[rr];
             dot = fmaf(csrow[rr], x[rr], dot);
             xr = fmaf(rhs0[rr], x[rr], xr);
             yy = fmaf(S.y[rr], S.y[rr], yy);
@@ -767,25 +553,36 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
     const float lb = P.lambda_bias_row ? P.lambda_bias_row[row] : P.lambda_bias_scalar;
     const float bnew = (sumr - dot) / (nnz + lb + ALS_EPS);
     const float bold = P.bias_self[row];            // read before the store: bias_out may alias bias_self
-    __builtin_amdgcn_sched_barrier(0);
-    if (lane == 0) P.bias_out[row] = bnew;
+    float st1 = 0.f, st2 = 0.f;
     if (P.stat_out) {
         // residuals of this row with the new x and bias, in closed form (DESIGN.md "Statistics"):
         //   sum d   = sum rho - nnz b - (F^T 1).x
         //   sum d^2 = sum (rho - b)^2 - 2 x.F^T(rho - b) + x^T G x,   x^T G x = |y|^2 - lambda |x|^2
         xr = wave_sum(xr); yy = wave_sum(yy); xx = wave_sum(xx);
-        if (lane == 0) {
-            // rhs0 was formed with the old bias (bold)
-            // the combination is a difference of large sums: in double (the inputs are fp32 sums; K1-f64 is the
-            // mode for fits whose residuals are ~1e-4 of the ratings)
-            const double bn = bnew, dt = dot;
-            const double s1 = (double)sumr - (double)nnz * bn;
-            const double s2 = (double)sumr2 - 2.0 * bn * (double)sumr + (double)nnz * bn * bn;
-            const double cross = (double)xr + ((double)bold - bn) * dt;
-            const double quad = (double)yy - (double)lam * (double)xx;
-            P.stat_out[2 * r64] = (float)(s1 - dt);
-            P.stat_out[2 * r64 + 1] = (float)(s2 - 2.0 * cross + quad);
+        // rhs0 was formed with the old bias (bold).  The combination is a difference of large sums: in double, but
+        // its inputs are fp32 sums (1e-7 relative each) - once the residuals are so small that less than three of
+        // those seven digits survive the cancellation (train RMSE below ~3 % of the ratings' spread: the over-fitted
+        // small-lambda corner) the row goes to the fp64 kernel as well when the call allows it (cond_limit > 0)
+        const double bn = bnew, dt = dot;
+        const double s1 = (double)sumr - (double)nnz * bn;
+        const double s2 = (double)sumr2 - 2.0 * bn * (double)sumr + (double)nnz * bn * bn;
+        const double cross = (double)xr + ((double)bold - bn) * dt;
+        const double quad = (double)yy - (double)lam * (double)xx;
+        const double sd2 = s2 - 2.0 * cross + quad;
+        if (P.cond_limit > 0.f && !(sd2 >= 1e-3 * s2)) {
+            if (lane == 0) P.redo_rows[atomicAdd(P.redo_count, 1)] = row;
+            return;
         }
+        st1 = (float)(s1 - dt);
+        st2 = (float)sd2;
+    }
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr)
+        if (lane + 64 * rr < KP) P.X_out[r64 * P.ld + colrow[rr]] = x[rr];
+    __builtin_amdgcn_sched_barrier(0);
+    if (lane == 0) {
+        P.bias_out[row] = bnew;
+        if (P.stat_out) { P.stat_out[2 * r64] = st1; P.stat_out[2 * r64 + 1] = st2; }
     }
 }
 
@@ -811,11 +608,13 @@ void k_row_tasks(const als_row_solve_params P) {
     const float mu = (float)(*P.mu);
     const float bself = P.bias_self[row];
 
+    const float S = (MODE != 0) ? P.F_scale[0] : 1.f;
+
     RowAcc<KB> A;
     A.zero();
     if (!(P.reserved0 & 1))        // reserved0: ablation flags for profiling builds, 0 in production
         gram_accumulate<KB, MODE>(A, P.indices + beg, P.vals + beg, len, P.F, P.ld, P.F_zero_row,
-                                  P.bias_other, mu, bself, lane, lds_all + wave * C::LDS_FLOATS);
+                                  P.bias_other, mu, bself, lane, lds_all + wave * C::LDS_FLOATS, S);
     if (slot >= 0) {
         store_partial<KB>(A, (float*)P.workspace + (size_t)slot * C::SLOT_ITEMS * 64, lane);
         return;
@@ -828,8 +627,8 @@ void k_row_tasks(const als_row_solve_params P) {
 //
 //   (F^T F + l I) x = F^T r   <=>   x = F^T w,  (F F^T + l I) w = r        (l = lambda + 1e-10)
 //
-// The n x n system (n <= 64) is built on the bf16 matrix cores exactly like the Gram - ratings on both
-// MFMA axes, the k factor columns as the contraction index, same exact 3-way split - and solved by the
+// The n x n system (n <= 64) is built on the fp16 matrix cores exactly like the Gram - ratings on both
+// MFMA axes, the k factor columns as the contraction index, same 2-way split - and solved by the
 // k = 64 machinery above (blocked Cholesky of a 64 x 64 matrix held in MFMA accumulators; rows past n are
 // identity).  Everything the row needs follows from w in closed form, since F x = F F^T w = r - l w:
 //   bias_new = (n b_old + l sum w) / (n + lambda_b + 1e-10)
@@ -866,11 +665,12 @@ __device__ __forceinline__ void row_dual(const als_row_solve_params& P, int row,
         off[I] = bperm_i(idx_l[(16 * I) >> 6], (16 * I + c) & 63) * P.ld;
 
     // K = F F^T: rating block I on the M axis, J <= I on the N axis, 32 factor columns per MFMA
+    const float Sc = P.F_scale[0];
     RowAcc<NB> A;
     A.zero();
     for (int s = 0; s < NSLAB; ++s) {
         const bool in = 32 * s + 8 * q < KP;         // a lane's 8 columns are all inside or all outside
-        i32x4 H[NB], M[NB], L[NB];
+        i32x4 H[NB], L[NB];
 #pragma unroll
         for (int I = 0; I < NB; ++I) {
             float f[8];
@@ -884,9 +684,9 @@ __device__ __forceinline__ void row_dual(const als_row_solve_params& P, int row,
             }
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
-                int hw, mw, lw;
-                split3(f[e], f[e + 1], hw, mw, lw);
-                H[I][e >> 1] = hw; M[I][e >> 1] = mw; L[I][e >> 1] = lw;
+                int hw, lw;
+                split2(f[e], f[e + 1], Sc, hw, lw);
+                H[I][e >> 1] = hw; L[I][e >> 1] = lw;
             }
         }
 #pragma unroll
@@ -895,17 +695,19 @@ __device__ __forceinline__ void row_dual(const als_row_solve_params& P, int row,
             for (int bj = 0; bj <= bi; ++bj) {
                 if (bi >= nblk) continue;
                 f32x4 acc = A.acc[blk_idx(bi, bj)];
-                const bf16x8 hi = __builtin_bit_cast(bf16x8, H[bi]), hj = __builtin_bit_cast(bf16x8, H[bj]);
-                const bf16x8 mi = __builtin_bit_cast(bf16x8, M[bi]), mj = __builtin_bit_cast(bf16x8, M[bj]);
-                const bf16x8 li = __builtin_bit_cast(bf16x8, L[bi]), lj = __builtin_bit_cast(bf16x8, L[bj]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(li, hj, acc, 0, 0, 0);     // smallest terms first
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, lj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mi, mj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mi, hj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, mj, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, hj, acc, 0, 0, 0);
+                const h16x8 hi = __builtin_bit_cast(h16x8, H[bi]), hj = __builtin_bit_cast(h16x8, H[bj]);
+                const h16x8 li = __builtin_bit_cast(h16x8, L[bi]), lj = __builtin_bit_cast(h16x8, L[bj]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(li, hj, acc, 0, 0, 0);     // smallest terms first
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, lj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, hj, acc, 0, 0, 0);
                 A.acc[blk_idx(bi, bj)] = acc;
             }
+    }
+    mfma_results_settle();
+    {
+        const float un = P.F_scale[1];               // S^2 K -> K
+#pragma unroll
+        for (int a = 0; a < KCfg<NB>::NACC; ++a) A.acc[a] *= un;
     }
     // + l I on the rows in use, identity on the padding rows (their rows / columns of K are zero)
     const float lam = (P.lambda_row ? P.lambda_row[row] : P.lambda_scalar) + ALS_EPS;
@@ -919,7 +721,13 @@ __device__ __forceinline__ void row_dual(const als_row_solve_params& P, int row,
 #pragma unroll
     for (int ss = 0; ss < NS; ++ss) { S.b[ss] = r_l[ss]; S.di[ss] = 0.f; S.y[ss] = 0.f; }
     chol_panels<NB, 0, true>(A, S, Ls, lane);
-    if (!chol_spd<NB>(S, lane) && lane == 0) atomicMax(P.status, row + 1);
+    {
+        // (F F^T + l I and F^T F + l I share their spectrum up to the multiplicity of l: the same condition estimate)
+        const bool spd = chol_spd<NB>(S, lane);
+        if (P.cond_limit > 0.f) {
+            if (row_needs_f64<NB>(S, P, row, spd, lane)) return;
+        } else if (!spd && lane == 0) atomicMax(P.status, row + 1);
+    }
     float w[NS];
     backward_solve<NB>(Ls, S, w, lane);               // w_t in lane t & 63, slot t >> 6 (0 past len)
 
@@ -1050,6 +858,57 @@ void k_sum_slots(const als_long_row* __restrict__ long_rows, float* __restrict__
     w0[0] = acc;
 }
 
+// Scale of the f16x2 operand split (split2): S = 2^j with S max|F| in [2^14, 2^15), clamped to 2^-60 ... 2^60, and
+// 1 / S^2.  scale[2] (running maximum of the |F| bit patterns) and scale[3] (ticket counter) are zero on entry and
+// are left zero by the workgroup that arrives last; a NaN / inf in F has the largest pattern and ends as a NaN Gram,
+// which the factorisation reports as "not positive definite" - as without the scaling.
+__global__ __launch_bounds__(256)
+void k_factor_scale(const float* __restrict__ F, int64_t n4, float* __restrict__ scale, int32_t* __restrict__ redo_count) {
+    __shared__ uint32_t wmax[4];
+    const f32x4* __restrict__ F4 = reinterpret_cast<const f32x4*>(F);
+    uint32_t m = 0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += 4 * stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = (i + u * stride < n4) ? F4[i + u * stride] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = max(m, (uint32_t)__float_as_int(v[u][e]) & 0x7FFFFFFFu);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t* w = reinterpret_cast<uint32_t*>(scale);
+        atomicMax(&w[2], max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+        __threadfence();
+        if (atomicAdd(&w[3], 1u) == gridDim.x - 1) {
+            __threadfence();
+            const uint32_t mx = atomicMax(&w[2], 0u);
+            const int e = (int)(mx >> 23);
+            const int se = min(max(268 - e, 67), 187);
+            scale[0] = __int_as_float(se << 23);
+            scale[1] = __int_as_float((381 - 2 * se) << 23);
+            atomicExch(&w[2], 0u);
+            atomicExch(&w[3], 0u);
+            if (redo_count) *redo_count = 0;        // (the call's list of rows for the fp64 kernel starts empty)
+        }
+    }
+}
+
+int launch_factor_scale(const float* F, int64_t nfloats, float* scale, int32_t* redo_count, hipStream_t st) {
+    const int64_t n4 = nfloats / 4;
+    const unsigned grid = (unsigned)min((int64_t)512, max((int64_t)1, (n4 + 1023) / 1024));
+    hipLaunchKernelGGL(k_factor_scale, dim3(grid), dim3(256), 0, st, F, n4, scale, redo_count);
+    return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
+}
+
+__global__ void k_reset_word(int32_t* w) { *w = 0; }
+
 template <int KB>
 int launch_row_solve(const als_row_solve_params* p, hipStream_t st) {
     using C = KCfg<KB>;
@@ -1057,7 +916,7 @@ int launch_row_solve(const als_row_solve_params* p, hipStream_t st) {
     // (see k_row_dual): `ndual_tail` whole rows of at most 64 ratings, preceded - k > 96 only, where it is the
     // smaller system - by `ndual_mid` whole rows of 65 ... 96 ratings.  Any by-product output, extra
     // right-hand side or diagonal, the f32 Gram mode or an ablation flag keeps every row primal.
-    const bool plain = p->gram_mode == ALS_GRAM_BF16X3 && p->reserved0 == 0 && p->X_out && p->bias_out &&
+    const bool plain = p->gram_mode == ALS_GRAM_F16X2 && p->reserved0 == 0 && p->X_out && p->bias_out &&
                        !p->gram_out && !p->factor_out && !p->rhs_out && !p->colsum_out && !p->sumr_out &&
                        !p->sumr2_out && !p->rhs_extra && !p->diag_extra;
     int64_t ntail = 0, nmid = 0;
@@ -1070,11 +929,7 @@ int launch_row_solve(const als_row_solve_params* p, hipStream_t st) {
         als_row_solve_params q = *p;
         q.ntasks = nprimal;
         const unsigned grid = (unsigned)((nprimal + C::WPW - 1) / C::WPW);
-        if ((KB == 7 || KB == 8) && p->gram_mode == ALS_GRAM_BF16X3 && p->reserved0 == 0 && p->scratch) {
-            // k = 112 / 128: two waves per row (row_pair.hip)
-            const int rc = als_row_pair_dispatch(&q, st);
-            if (rc != 0) return rc;
-        } else if (p->gram_mode == ALS_GRAM_BF16X3)
+        if (p->gram_mode == ALS_GRAM_F16X2)
             hipLaunchKernelGGL((k_row_tasks<KB, 1>), dim3(grid), dim3(64 * C::WPW), 0, st, q);
         else
             hipLaunchKernelGGL((k_row_tasks<KB, 0>), dim3(grid), dim3(64 * C::WPW), 0, st, q);
@@ -1099,6 +954,7 @@ int launch_row_solve(const als_row_solve_params* p, hipStream_t st) {
 }  // namespace
 
 int als_row_solve_f64_dispatch(const als_row_solve_params* p, hipStream_t st);     // row_solve_f64.hip
+int als_row_redo_f64_dispatch(const als_row_solve_params* p, hipStream_t st);
 
 extern "C" int als_version(void) { return ALS_HIP_VERSION; }
 extern "C" int als_padded_k(int k) { return (k < 1 || k > ALS_MAX_K) ? ALS_E_BADK : 16 * ((k + 15) / 16); }
@@ -1115,13 +971,18 @@ extern "C" int64_t als_partial_slot_bytes(int k) {
     return (int64_t)(KB * (KB + 1) / 2 * 4 + 2 * KB + 2) * 64 * sizeof(float);
 }
 
+extern "C" int als_factor_scale(const float* F, int64_t nfloats, float* scale, void* stream) {
+    if (!F || !scale || nfloats < 0 || (nfloats & 3) || ((uintptr_t)F & 15)) return ALS_E_BADARG;
+    return launch_factor_scale(F, nfloats, scale, nullptr, (hipStream_t)stream);
+}
+
 extern "C" int als_row_solve(const als_row_solve_params* p, void* stream) {
     if (!p) return ALS_E_BADARG;
     const int ld = als_padded_k(p->k);
     if (ld < 0) return ALS_E_BADK;
     if (p->ld != ld || !p->indptr || !p->indices || !p->vals || !p->F || !p->bias_self ||
         !p->bias_other || !p->mu || !p->status || p->ntasks < 0 || p->nlong < 0 || p->F_zero_row < 0 ||
-        (p->gram_mode != ALS_GRAM_F32 && p->gram_mode != ALS_GRAM_BF16X3 && p->gram_mode != ALS_GRAM_F64) ||
+        (p->gram_mode != ALS_GRAM_F32 && p->gram_mode != ALS_GRAM_F16X2 && p->gram_mode != ALS_GRAM_F64) ||
         (int64_t)p->F_zero_row * ld >= ((int64_t)1 << 31))
         return ALS_E_BADARG;
     if (p->ntasks > 0 && !p->tasks) return ALS_E_BADARG;
@@ -1133,17 +994,37 @@ extern "C" int als_row_solve(const als_row_solve_params* p, void* stream) {
     }
     hipStream_t st = (hipStream_t)stream;
     if (p->gram_mode == ALS_GRAM_F64) return als_row_solve_f64_dispatch(p, st);
-    switch (ld / 16) {
-        case 1: return launch_row_solve<1>(p, st);
-        case 2: return launch_row_solve<2>(p, st);
-        case 3: return launch_row_solve<3>(p, st);
-        case 4: return launch_row_solve<4>(p, st);
-        case 5: return launch_row_solve<5>(p, st);
-        case 6: return launch_row_solve<6>(p, st);
-        case 7: return launch_row_solve<7>(p, st);
-        case 8: return launch_row_solve<8>(p, st);
-        case 9: return launch_row_solve<9>(p, st);
-        case 10: return launch_row_solve<10>(p, st);
+    const bool redo = p->cond_limit > 0.f;
+    if (redo && (!p->redo_count || !p->redo_rows)) return ALS_E_BADARG;
+    bool counter_reset = false;
+    if (p->gram_mode == ALS_GRAM_F16X2) {
+        if (!p->F_scale) return ALS_E_BADARG;
+        if (!p->F_scale_ready) {
+            const int rc = launch_factor_scale(p->F, ((int64_t)p->F_zero_row + 1) * ld, p->F_scale,
+                                               redo ? p->redo_count : nullptr, st);
+            if (rc != 0) return rc;
+            counter_reset = true;
+        }
     }
-    return ALS_E_BADK;
+    if (redo && !counter_reset) hipLaunchKernelGGL(k_reset_word, dim3(1), dim3(1), 0, st, p->redo_count);
+    int rc = ALS_E_BADK;
+#ifdef ALS_KB_ONLY      // development builds (profiles/ab_builds.sh): one model width only, a tenth of the compile time
+    if (ld / 16 == ALS_KB_ONLY) rc = launch_row_solve<ALS_KB_ONLY>(p, st);
+#else
+    switch (ld / 16) {
+        case 1: rc = launch_row_solve<1>(p, st); break;
+        case 2: rc = launch_row_solve<2>(p, st); break;
+        case 3: rc = launch_row_solve<3>(p, st); break;
+        case 4: rc = launch_row_solve<4>(p, st); break;
+        case 5: rc = launch_row_solve<5>(p, st); break;
+        case 6: rc = launch_row_solve<6>(p, st); break;
+        case 7: rc = launch_row_solve<7>(p, st); break;
+        case 8: rc = launch_row_solve<8>(p, st); break;
+        case 9: rc = launch_row_solve<9>(p, st); break;
+        case 10: rc = launch_row_solve<10>(p, st); break;
+    }
+#endif
+    // rows the fp32 kernels flagged (condition estimate above the limit, or a broken-down factorisation): fp64
+    if (rc == 0 && redo) rc = als_row_redo_f64_dispatch(p, st);
+    return rc;
 }

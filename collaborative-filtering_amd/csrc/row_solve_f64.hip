@@ -179,24 +179,30 @@ __device__ __forceinline__ void finish_row_f64(const als_row_solve_params& P, in
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) colrow[rr] = perm_to_col<KB>(min(lane + 64 * rr, KP - 1));
 
-    if (P.gram_out) {           // F^T F without lambda, perm space, lower 16x16 blocks (fp32, as the fp32 kernel)
+    // by-products: fp32 as the fp32 kernel writes them, or - byproducts_f64 - as doubles for the fp64 W-step
+    const bool b64 = P.byproducts_f64 != 0;
+    if (P.gram_out) {           // F^T F without lambda, perm space, lower 16x16 blocks
         float* G = P.gram_out + r64 * KP * KP;
+        double* G64 = (double*)P.gram_out + r64 * KP * KP;
         for (int I = 0; I < KB; ++I)
             for (int K = 0; K <= I; ++K)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    G[(16 * I + q + 4 * i) * KP + 16 * K + c] = (float)img[blk64(I, K) * 256 + (q + 4 * i) * 16 + c];
+                for (int i = 0; i < 4; ++i) {
+                    const double v = img[blk64(I, K) * 256 + (q + 4 * i) * 16 + c];
+                    if (b64) G64[(16 * I + q + 4 * i) * KP + 16 * K + c] = v;
+                    else G[(16 * I + q + 4 * i) * KP + 16 * K + c] = (float)v;
+                }
     }
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
         const int i = lane + 64 * rr;
         if (i < KP) {
-            if (P.rhs_out) P.rhs_out[r64 * KP + i] = (float)rhs_p[rr];
-            if (P.colsum_out) P.colsum_out[r64 * KP + i] = (float)cs_p[rr];
+            if (P.rhs_out) { if (b64) ((double*)P.rhs_out)[r64 * KP + i] = rhs_p[rr]; else P.rhs_out[r64 * KP + i] = (float)rhs_p[rr]; }
+            if (P.colsum_out) { if (b64) ((double*)P.colsum_out)[r64 * KP + i] = cs_p[rr]; else P.colsum_out[r64 * KP + i] = (float)cs_p[rr]; }
         }
     }
-    if (P.sumr_out && lane == 0) P.sumr_out[row] = (float)sumr;
-    if (P.sumr2_out && lane == 0) P.sumr2_out[row] = (float)sumr2;
+    if (P.sumr_out && lane == 0) { if (b64) ((double*)P.sumr_out)[row] = sumr; else P.sumr_out[row] = (float)sumr; }
+    if (P.sumr2_out && lane == 0) { if (b64) ((double*)P.sumr2_out)[row] = sumr2; else P.sumr2_out[row] = (float)sumr2; }
 
     // regulariser on the diagonal; padded columns get 1 (scripts/als.py:426, 450-455: lambda + 1e-10 (+ alpha D_i))
     const double lam = (double)(P.lambda_row ? P.lambda_row[row] : P.lambda_scalar) + 1e-10
@@ -300,6 +306,7 @@ __device__ __forceinline__ void finish_row_f64(const als_row_solve_params& P, in
         // symmetric completion of L with 1 / L_ii on the diagonal, perm space, fp32 (input of the sweep kernels):
         // M[p][i] = L[i][p] (p < i), L[p][i] (p > i)
         float* M = P.factor_out + r64 * KP * KP;
+        double* M64 = (double*)P.factor_out + r64 * KP * KP;
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) {
             const int i = lane + 64 * rr;
@@ -307,7 +314,8 @@ __device__ __forceinline__ void finish_row_f64(const als_row_solve_params& P, in
                 for (int p = 0; p < KP; ++p) {
                     const int hi = max(p, i), lo = min(p, i);
                     const double v = (p == i) ? dinv[rr] : img[blk64(hi >> 4, lo >> 4) * 256 + (hi & 15) * 16 + (lo & 15)];
-                    __builtin_nontemporal_store((float)v, M + p * KP + i);
+                    if (b64) __builtin_nontemporal_store(v, M64 + p * KP + i);
+                    else __builtin_nontemporal_store((float)v, M + p * KP + i);
                 }
             }
         }
@@ -441,6 +449,55 @@ void k_row_long_f64(const als_row_solve_params P) {
     finish_row_f64<KB>(P, lr.row, img, rhs_p, cs_p, sumr, sumr2, lane);
 }
 
+// Rows handed over by the fp32 kernels (als_row_solve_params::cond_limit): the first *redo_count entries of
+// redo_rows, each redone as ONE task whatever its length (no segments: the fp64 Gram has no accumulation-length
+// issue and such rows are few), by a fixed grid of waves that walk the list - the count is only known on the
+// device.  Same outputs as the fp32 kernel would have written.
+template <int KB>
+__global__ __launch_bounds__(64)
+void k_row_redo_f64(const als_row_solve_params P) {
+    using C = F64Cfg<KB>;
+    __shared__ __attribute__((aligned(16))) double img[C::IMG];
+    const int lane = threadIdx.x;
+    const int count = *P.redo_count;
+    const double mu = *P.mu;
+    for (int e = blockIdx.x; e < count; e += gridDim.x) {
+        const int row = P.redo_rows[e];
+        const int64_t beg = P.indptr[row];
+        const int len = (int)(P.indptr[row + 1] - beg);
+        const double bself = (double)P.bias_self[row];
+        double rhs[KB], cs[KB], sumr = 0.0, sumr2 = 0.0;
+#pragma unroll
+        for (int b = 0; b < KB; ++b) { rhs[b] = 0.0; cs[b] = 0.0; }
+        gram_passes_f64<KB, 0, true>(P, beg, len, mu, bself, img, rhs, cs, sumr, sumr2, lane);
+        double rhs_p[C::NR], cs_p[C::NR];
+        to_rows_f64<KB>(rhs, cs, rhs_p, cs_p, lane);
+        sumr = wave_sum_f64(sumr);
+        sumr2 = wave_sum_f64(sumr2);
+        wave_lds_sync();
+        finish_row_f64<KB>(P, row, img, rhs_p, cs_p, sumr, sumr2, lane);
+        wave_lds_sync();                    // the image is reused by the next row
+    }
+}
+
+template <int KB>
+int launch_row_redo_f64(const als_row_solve_params* p, hipStream_t st) {
+    // enough waves to fill the device when many rows were flagged, cheap when none was (they exit at once)
+    static int grid_of[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ALS_E_LAUNCH;
+    if (grid_of[dev] == 0) {
+        int nb = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_row_redo_f64<KB>, 64, 0) != hipSuccess || nb < 1)
+            return ALS_E_LAUNCH;
+        grid_of[dev] = prop.multiProcessorCount * (nb > 8 ? 8 : nb);
+    }
+    hipLaunchKernelGGL(k_row_redo_f64<KB>, dim3((unsigned)grid_of[dev]), dim3(64), 0, st, *p);
+    return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
+}
+
 template <int KB>
 int launch_row_solve_f64(const als_row_solve_params* p, hipStream_t st) {
     using C = F64Cfg<KB>;
@@ -461,6 +518,23 @@ extern "C" int64_t als_partial_slot_bytes_f64(int k) {
     if (ld < 0) return ALS_E_BADK;
     const int KB = ld / 16;
     return (int64_t)(KB * (KB + 1) / 2 * 256 + 2 * ld + 2) * sizeof(double);
+}
+
+// called by als_row_solve (row_solve.hip) after the fp32 launches of a call with cond_limit > 0
+int als_row_redo_f64_dispatch(const als_row_solve_params* p, hipStream_t st) {
+    switch (p->ld / 16) {
+        case 1: return launch_row_redo_f64<1>(p, st);
+        case 2: return launch_row_redo_f64<2>(p, st);
+        case 3: return launch_row_redo_f64<3>(p, st);
+        case 4: return launch_row_redo_f64<4>(p, st);
+        case 5: return launch_row_redo_f64<5>(p, st);
+        case 6: return launch_row_redo_f64<6>(p, st);
+        case 7: return launch_row_redo_f64<7>(p, st);
+        case 8: return launch_row_redo_f64<8>(p, st);
+        case 9: return launch_row_redo_f64<9>(p, st);
+        case 10: return launch_row_redo_f64<10>(p, st);
+    }
+    return ALS_E_BADK;
 }
 
 // called by als_row_solve (row_solve.hip) after its argument checks when gram_mode == ALS_GRAM_F64

@@ -197,7 +197,7 @@ void k_history_final(const Norm4 a, const double* __restrict__ partials, const d
         const double m = *mu + mean_d;
         const double var = stats[1] / nnz - mean_d * mean_d;
         *mu = m;
-        row[0] = sqrt(var > 0.0 ? var : 0.0);
+        row[0] = sqrt(var < 0.0 ? 0.0 : var);          // (a NaN - no ratings at all - stays a NaN, as numpy's mean of nothing)
         for (int j = 0; j < 4; ++j) row[1 + j] = sqrt(red[j][0]);
         row[5] = m;
     }
@@ -266,7 +266,7 @@ extern "C" int als_sumsq(const float* x, int64_t n, double* partials, double* ou
 extern "C" int als_history_row(const float* U, int64_t nU, const float* V, int64_t nV, const float* b_u, int64_t nbu,
                                const float* b_i, int64_t nbi, const double* stats, int64_t nnz, double* mu,
                                double* partials, double* row, void* stream) {
-    if (!U || !V || !b_u || !b_i || !stats || !mu || !partials || !row || nnz < 1 || nU < 0 || nV < 0 || nbu < 0 || nbi < 0)
+    if (!U || !V || !b_u || !b_i || !stats || !mu || !partials || !row || nnz < 0 || nU < 0 || nV < 0 || nbu < 0 || nbi < 0)
         return ALS_E_BADARG;
     Norm4 a;
     const float* xs[4] = {U, V, b_u, b_i};

@@ -123,6 +123,124 @@ void k_w_item_vectors(int k, int64_t i0, int64_t i1, const float* __restrict__ g
     }
 }
 
+// The same per-item vectors from FLOAT64 by-products (als_w_params::f64: the V-step ran in fp64 and left its Gram,
+// right-hand side and column sums as doubles) - the accuracy path for feature projections with lambda_w ~ 0, where
+// the (d k)^2 system is singular up to the 1e-10 the reference adds and only an fp64-consistent assembly keeps its
+// null space clean (scripts/als.py:497-500).  Plain fp64 FMAs, one wave per item, every lane its own rows of G.
+__device__ __forceinline__ double gsym64(const double* __restrict__ G, int ld, int r, int c) {
+    return (r >= c) ? G[r * ld + c] : G[c * ld + r];
+}
+
+template <int KB, int NV>
+__device__ __forceinline__ void gsym_matvecs_f64(const double* __restrict__ G, const double* __restrict__ xs,
+                                                 double (&y)[NV][KCfg<KB>::NR], int nv, int lane) {
+    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) y[v][rr] = 0.0;
+    for (int c = 0; c < KP; ++c) {
+        double g[NR];
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) g[rr] = gsym64(G, KP, min(lane + 64 * rr, KP - 1), c);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (v < nv) {
+                const double x = xs[v * KP + c];
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) y[v][rr] = fma(g[rr], x, y[v][rr]);
+            }
+        }
+    }
+}
+
+template <int KB>
+__global__ __launch_bounds__(64)
+void k_w_item_vectors_f64(int k, int64_t i0, int64_t i1, const double* __restrict__ gram,
+                          const double* __restrict__ rhs, const double* __restrict__ colsum,
+                          const float* __restrict__ V, const float* __restrict__ b_new,
+                          const float* __restrict__ b_old, int nfeat, int D, const float* __restrict__ X,
+                          const int* __restrict__ feat_off, const double* __restrict__ W64,
+                          double* __restrict__ H, int64_t nrows_h) {
+    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR, NV = 9;
+    const int64_t i = i0 + blockIdx.x;
+    if (i >= i1) return;
+    const int lane = threadIdx.x;
+    const double* G = gram + i * KP * KP;
+    __shared__ double xs[NV * KP];
+    int p[NR], col[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        p[rr] = min(lane + 64 * rr, KP - 1);
+        col[rr] = perm_to_col<KB>(p[rr]);
+        const bool mine = lane + 64 * rr < KP;
+        double zsum = (double)V[i * KP + col[rr]];
+        for (int f = 0; f < NV - 1; ++f) {
+            double t = 0.0;
+            if (f < nfeat && col[rr] < k)
+                for (int a = feat_off[f]; a < feat_off[f + 1]; ++a) t = fma((double)X[i * D + a], W64[(int64_t)a * k + col[rr]], t);
+            zsum += t;
+            if (mine) xs[(f + 1) * KP + p[rr]] = t;
+        }
+        if (mine) xs[p[rr]] = zsum;                      // z = V + sum_f xw_f
+    }
+    wave_lds_sync();
+    double y[NV][NR];
+    gsym_matvecs_f64<KB, NV>(G, xs, y, nfeat + 1, lane);
+    const double db = (double)b_new[i] - (double)b_old[i];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        if (lane + 64 * rr < KP) {
+            const double g = rhs[i * KP + p[rr]] - db * colsum[i * KP + p[rr]] - y[0][rr];
+#pragma unroll
+            for (int f = 0; f < NV - 1; ++f)
+                if (f < nfeat) H[((int64_t)f * nrows_h + i) * KP + p[rr]] = g + y[f + 1][rr];
+        }
+    }
+}
+
+template <int KB>
+__global__ __launch_bounds__(64)
+void k_item_stats_f64(int64_t i0, int64_t i1, int ld, const double* __restrict__ gram, const double* __restrict__ rhs,
+                      const double* __restrict__ colsum, const double* __restrict__ sumr, const double* __restrict__ sumr2,
+                      const int64_t* __restrict__ indptr, const float* __restrict__ Z, const float* __restrict__ b_new,
+                      const float* __restrict__ b_old, float* __restrict__ stat_out) {
+    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR;
+    const int64_t i = i0 + blockIdx.x;
+    if (i >= i1) return;
+    const int lane = threadIdx.x;
+    const double* G = gram + i * KP * KP;
+    __shared__ double xs[KP];
+    int p[NR];
+    double z[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        p[rr] = min(lane + 64 * rr, KP - 1);
+        z[rr] = (lane + 64 * rr < KP) ? (double)Z[i * ld + perm_to_col<KB>(p[rr])] : 0.0;
+        if (lane + 64 * rr < KP) xs[p[rr]] = z[rr];
+    }
+    wave_lds_sync();
+    double y[1][NR];
+    gsym_matvecs_f64<KB, 1>(G, xs, y, 1, lane);
+    double zgz = 0.0, zr = 0.0, zc = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr)
+        if (lane + 64 * rr < KP) {
+            zgz += z[rr] * y[0][rr];
+            zr += z[rr] * rhs[i * KP + p[rr]];
+            zc += z[rr] * colsum[i * KP + p[rr]];
+        }
+    zgz = wave_sum_d(zgz); zr = wave_sum_d(zr); zc = wave_sum_d(zc);
+    if (lane == 0) {
+        const double n = (double)(indptr[i + 1] - indptr[i]);
+        const double b = b_new[i], bo = b_old[i], sr = sumr[i], sr2 = sumr2[i];
+        const double s1 = sr - n * b - zc;
+        const double s2 = (sr2 - 2.0 * b * sr + n * b * b) - 2.0 * (zr + (bo - b) * zc) + zgz;
+        stat_out[2 * i] = (float)s1;
+        stat_out[2 * i + 1] = (float)s2;
+    }
+}
+
 // Closed-form residual sums of one item when Z != V (features present), one wave per item:
 //   d = rho - b_new - u . z_i over the item's ratings, rho = r - mu - b_u
 //   sum d   = sum rho - n b_new - z . (U_i^T 1)
@@ -189,10 +307,10 @@ __device__ __forceinline__ void lower_block(int q, int& I, int& J) {
 // items: the tile's contributing items (w != 0) are compacted, in item order, into an LDS list, and the
 // list is consumed four items at a time so that 4 NACC independent loads are in flight per thread (a
 // serial `if (w == 0) continue` loop pays one dependent-load latency per item).  Fixed summation order.
-template <int KB>
+template <int KB, typename T>
 __global__ __launch_bounds__(256)
-void k_w_accumulate(int64_t i0, int64_t i1, int nchunks, const float* __restrict__ gram, int D, int foff, int d,
-                    const float* __restrict__ X, const float* __restrict__ Hf, double* __restrict__ partA,
+void k_w_accumulate(int64_t i0, int64_t i1, int nchunks, const T* __restrict__ gram, int D, int foff, int d,
+                    const float* __restrict__ X, const T* __restrict__ Hf, double* __restrict__ partA,
                     double* __restrict__ partB) {
     constexpr int KP = KCfg<KB>::KP, NACC = KCfg<KB>::NACC;
     __shared__ int l_item[256];
@@ -240,14 +358,14 @@ void k_w_accumulate(int64_t i0, int64_t i1, int nchunks, const float* __restrict
         __syncthreads();
         int n = 0;
         for (; n + 4 <= total; n += 4) {
-            float g[4][NACC], h[4];
+            T g[4][NACC], h[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t it = tile + l_item[n + u];
-                const float* G = gram + it * KP * KP;
+                const T* G = gram + it * KP * KP;
 #pragma unroll
                 for (int q = 0; q < NACC; ++q) g[u][q] = G[offT[q]];
-                h[u] = want_b ? Hf[it * KP + t] : 0.f;
+                h[u] = want_b ? Hf[it * KP + t] : (T)0;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -259,7 +377,7 @@ void k_w_accumulate(int64_t i0, int64_t i1, int nchunks, const float* __restrict
         }
         for (; n < total; ++n) {
             const int64_t it = tile + l_item[n];
-            const float* G = gram + it * KP * KP;
+            const T* G = gram + it * KP * KP;
             const double w64 = (double)l_w[n];
 #pragma unroll
             for (int q = 0; q < NACC; ++q) acc[q] += w64 * (double)G[offT[q]];
@@ -322,14 +440,25 @@ int launch_w(const als_w_params* p, hipStream_t st) {
     const int64_t nit = p->item_end - p->item_begin;
     if (nit <= 0) return 0;
     if (p->phase == 0) {
-        hipLaunchKernelGGL(k_w_item_vectors<KB>, dim3((unsigned)nit), dim3(64), 0, st, p->k, p->item_begin,
-                           p->item_end, p->gram, p->rhs, p->colsum, p->V, p->b_new, p->b_old, p->nfeat, p->D,
-                           p->X, p->feat_off, p->W, p->H, p->nrows_h);
+        if (p->f64)
+            hipLaunchKernelGGL(k_w_item_vectors_f64<KB>, dim3((unsigned)nit), dim3(64), 0, st, p->k, p->item_begin,
+                               p->item_end, (const double*)p->gram, (const double*)p->rhs, (const double*)p->colsum,
+                               p->V, p->b_new, p->b_old, p->nfeat, p->D, p->X, p->feat_off, (const double*)p->W,
+                               (double*)p->H, p->nrows_h);
+        else
+            hipLaunchKernelGGL(k_w_item_vectors<KB>, dim3((unsigned)nit), dim3(64), 0, st, p->k, p->item_begin,
+                               p->item_end, p->gram, p->rhs, p->colsum, p->V, p->b_new, p->b_old, p->nfeat, p->D,
+                               p->X, p->feat_off, p->W, p->H, p->nrows_h);
     } else {
         const int d = p->feat_d, npairs = d * (d + 1) / 2;
-        hipLaunchKernelGGL(k_w_accumulate<KB>, dim3(npairs, p->nchunks), dim3(256), 0, st, p->item_begin,
-                           p->item_end, p->nchunks, p->gram, p->D, p->feat_col0, d, p->X,
-                           p->H + (int64_t)p->feat_index * p->nrows_h * KP, p->partA, p->partB);
+        if (p->f64)
+            hipLaunchKernelGGL((k_w_accumulate<KB, double>), dim3(npairs, p->nchunks), dim3(256), 0, st, p->item_begin,
+                               p->item_end, p->nchunks, (const double*)p->gram, p->D, p->feat_col0, d, p->X,
+                               (const double*)p->H + (int64_t)p->feat_index * p->nrows_h * KP, p->partA, p->partB);
+        else
+            hipLaunchKernelGGL((k_w_accumulate<KB, float>), dim3(npairs, p->nchunks), dim3(256), 0, st, p->item_begin,
+                               p->item_end, p->nchunks, p->gram, p->D, p->feat_col0, d, p->X,
+                               p->H + (int64_t)p->feat_index * p->nrows_h * KP, p->partA, p->partB);
         hipLaunchKernelGGL(k_w_reduce<KB>, dim3(npairs, KCfg<KB>::NACC + 1), dim3(256), 0, st, p->k, p->nchunks, d, p->partA, p->partB,
                            p->A_out, p->B_out);
     }
@@ -380,6 +509,38 @@ int launch_item_stats(int64_t i0, int64_t i1, int ld, const float* gram, const f
     return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
 }
 }  // namespace
+
+namespace {
+template <int KB>
+int launch_item_stats_f64(int64_t i0, int64_t i1, int ld, const double* gram, const double* rhs, const double* colsum,
+                          const double* sumr, const double* sumr2, const int64_t* indptr, const float* Z,
+                          const float* b_new, const float* b_old, float* stat_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_item_stats_f64<KB>, dim3((unsigned)(i1 - i0)), dim3(64), 0, st, i0, i1, ld, gram, rhs, colsum,
+                       sumr, sumr2, indptr, Z, b_new, b_old, stat_out);
+    return hipGetLastError() == hipSuccess ? 0 : ALS_E_LAUNCH;
+}
+}  // namespace
+
+extern "C" int als_item_stats_f64(int k, int ld, int64_t item_begin, int64_t item_end, const double* gram,
+                                  const double* rhs, const double* colsum, const double* sumr, const double* sumr2,
+                                  const int64_t* indptr, const float* Z, const float* b_new, const float* b_old,
+                                  float* stat_out, void* stream) {
+    const int kp = als_padded_k(k);
+    if (kp < 0) return ALS_E_BADK;
+    if (ld != kp || item_end < item_begin || !gram || !rhs || !colsum || !sumr || !sumr2 || !indptr || !Z ||
+        !b_new || !b_old || !stat_out)
+        return ALS_E_BADARG;
+    if (item_end == item_begin) return 0;
+    hipStream_t st = (hipStream_t)stream;
+#define ALS_IS64(KBV) case KBV: return launch_item_stats_f64<KBV>(item_begin, item_end, ld, gram, rhs, colsum, sumr, \
+                                                                 sumr2, indptr, Z, b_new, b_old, stat_out, st)
+    switch (ld / 16) {
+        ALS_IS64(1); ALS_IS64(2); ALS_IS64(3); ALS_IS64(4); ALS_IS64(5); ALS_IS64(6); ALS_IS64(7); ALS_IS64(8); ALS_IS64(9);
+        ALS_IS64(10);
+    }
+#undef ALS_IS64
+    return ALS_E_BADK;
+}
 
 extern "C" int als_item_stats(int k, int ld, int64_t item_begin, int64_t item_end, const float* gram,
                               const float* rhs, const float* colsum, const float* sumr, const float* sumr2,

@@ -171,22 +171,37 @@ def shard_bounds(nrows: int, world: int, multiple: int = 1) -> Tuple[int, List[T
     return per, [(min(r * per, nrows), min((r + 1) * per, nrows)) for r in range(world)]
 
 
-def shard_bounds_nnz(indptr: np.ndarray, world: int, chunks: int = 1):
-    """Contiguous row shards balanced by number of ratings: shard r ends at the first row
-    where the running count reaches (r + 1) / world of the total.  Returns ([(begin, end)] per rank,
-    [[(begin, end)] * chunks per rank]): every shard is cut the same way into `chunks` sub-ranges (the U-step
-    solves and all-gathers them one after the other).  Deterministic from `indptr` alone, so every rank computes
-    the same tables.  Row counts differ between shards; empty shards are possible (world > rows)."""
+def row_cost_weight(k: int) -> float:
+    """Fixed cost of one row of als_row_solve in units of one rating's cost: the k x k factorisation, the two
+    substitutions and the row's set-up against the per-rating Gram work.  Fitted from the one-GPU phase times at
+    k = 64 (Cholesky + substitutions + fixed 3.4 ms per 10^6 rows against 3.4 ms per 10^8
+    ratings -> ~100) and scaled with k (per row ~k^2 vector + k^3 matrix work, per rating ~k^2)."""
+    return 1.6 * float(k)
+
+
+def shard_bounds_nnz(indptr: np.ndarray, world: int, chunks: int = 1, row_cost: float = 0.0):
+    """Contiguous row shards balanced by COST = ratings + row_cost * rows (row_cost = 0:
+    by ratings alone): shard r ends at the first row where the running cost reaches (r + 1) / world of the total.
+    Returns ([(begin, end)] per rank, [[(begin, end)] * chunks per rank]): every shard is cut the same way into
+    `chunks` sub-ranges (the U-step solves and all-gathers them one after the other).  Deterministic from
+    `indptr` alone, so every rank computes the same tables.  Row counts differ between shards; empty shards are
+    possible (world > rows).  Only rows with ratings cost anything (empty rows are not solved)."""
     indptr = np.asarray(indptr, dtype=np.int64)
     nrows = len(indptr) - 1
     total = int(indptr[-1])
+    if row_cost > 0.0 and nrows:
+        busy = np.zeros(nrows + 1, dtype=np.float64)
+        np.cumsum(np.diff(indptr) > 0, out=busy[1:])
+        cost = indptr.astype(np.float64) + float(row_cost) * busy
+    else:
+        cost = indptr.astype(np.float64)
 
     def cut(lo: int, hi: int, parts: int):
-        n_lo, n_hi = int(indptr[lo]), int(indptr[hi])
+        c_lo, c_hi = float(cost[lo]), float(cost[hi])
         edges = [lo]
         for j in range(1, parts):
-            target = n_lo + (n_hi - n_lo) * j / parts
-            e = int(np.searchsorted(indptr, target, side="left"))
+            target = c_lo + (c_hi - c_lo) * j / parts
+            e = int(np.searchsorted(cost, target, side="left"))
             edges.append(min(max(e, edges[-1]), hi))
         edges.append(hi)
         return [(edges[j], edges[j + 1]) for j in range(parts)]
@@ -197,6 +212,13 @@ def shard_bounds_nnz(indptr: np.ndarray, world: int, chunks: int = 1):
     else:
         bounds = cut(0, nrows, world)
     return bounds, [cut(b, e, chunks) for b, e in bounds]
+
+
+def shard_costs(indptr: np.ndarray, bounds, row_cost: float) -> np.ndarray:
+    """Predicted cost (ratings + row_cost * non-empty rows) of every shard of `bounds`."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    lens = np.diff(indptr)
+    return np.array([float(indptr[e] - indptr[b]) + row_cost * float(np.count_nonzero(lens[b:e])) for b, e in bounds])
 
 
 def build_similarity_dense(X: np.ndarray, topk: Optional[int], eps: float) -> np.ndarray:

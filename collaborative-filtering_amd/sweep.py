@@ -128,7 +128,7 @@ class SweepDriver:
             model._fit_sides(f.csr, f.csc, self.features, es_tol, es_min_iters, verbose_fit, self._graph_for(cfg),
                              S_trusted=True)
             with torch.cuda.device(self.dev):
-                pred = model._eng.predict_pairs(f.us, f.is_, self.features).cpu().numpy().astype(np.float64)
+                pred = model._eng.predict_pairs(f.us, f.is_, self.features, features_of_fit=True).cpu().numpy().astype(np.float64)
             rmse = rmse_at(f.truth, pred)
             n_run = len(model.history.get("train_rmse", []))
             fold_scores.append(rmse)

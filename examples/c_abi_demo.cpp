@@ -78,8 +78,11 @@ int main() {
     std::vector<int32_t> st(1, 0); int32_t* d_status = upload(st);
     if (!d_ptr || !d_idx || !d_val || !d_F || !d_bi || !d_bu || !d_tasks || !d_mu || !d_X || !d_status) return 2;
 
+    // operand scale of the f16x2 Gram: ALS_FSCALE_FLOATS floats, zero before the first use (als_row_solve fills it)
+    std::vector<float> fs(ALS_FSCALE_FLOATS, 0.f); float* d_fscale = upload(fs);
+    if (!d_fscale) return 2;
     als_row_solve_params p = {};
-    p.k = k; p.ld = ld; p.nrows = m; p.F_zero_row = n; p.gram_mode = ALS_GRAM_BF16X3;
+    p.k = k; p.ld = ld; p.nrows = m; p.F_zero_row = n; p.gram_mode = ALS_GRAM_F16X2; p.F_scale = d_fscale;
     p.indptr = d_ptr; p.indices = d_idx; p.vals = d_val; p.F = d_F;
     p.bias_self = d_bu; p.bias_other = d_bi; p.mu = d_mu;
     p.lambda_scalar = lam; p.lambda_bias_scalar = lam_b;

@@ -34,14 +34,15 @@
 extern "C" {
 #endif
 
-#define ALS_HIP_VERSION 101
+#define ALS_HIP_VERSION 102
 
 #define ALS_E_BADARG   (-1)
 #define ALS_E_BADK     (-2)   /* k outside 1..ALS_MAX_K */
 #define ALS_E_LAUNCH   (-3)   /* hipGetLastError() != hipSuccess after a launch */
 
 #define ALS_GRAM_F32    0
-#define ALS_GRAM_BF16X3 1
+#define ALS_GRAM_F16X2  1     /* 2-way fp16 split of the scaled floats, three cross products on v_mfma_f32_16x16x32_f16,
+                                 fp32 accumulate: fp32-equivalent (default) */
 #define ALS_GRAM_F64    2     /* fp64 Gram (v_mfma_f64_16x16x4_f64), fp64 Cholesky and substitutions: the
                                  reference's arithmetic type; x and the bias are rounded to fp32 on store */
 
@@ -119,9 +120,10 @@ typedef struct als_row_solve_params {
                                    and every indices[t]*ld must be < 2^31 */
     int32_t reserved0;          /* 0 (profiling builds: phase-ablation flags) */
     int32_t gram_mode;          /* ALS_GRAM_F32: v_mfma_f32_16x16x4_f32 on the gathered floats;
-                                   ALS_GRAM_BF16X3: exact 3-way bf16 split of every float, six cross
-                                   products on v_mfma_f32_16x16x32_bf16, fp32 accumulate (same accuracy
-                                   class, the matrix cores run beside the VALU);
+                                   ALS_GRAM_F16X2: every float times S (a power of two, als_factor_scale) is split
+                                   into two fp16 terms by rounding to nearest (error <= 2^-23), three cross
+                                   products on v_mfma_f32_16x16x32_f16, fp32 accumulate (same accuracy
+                                   class, the 16-bit matrix cores run beside the VALU); needs F_scale;
                                    ALS_GRAM_F64: everything in fp64 (row_solve_f64.hip) - for lambda << 1 with
                                    rank-deficient rows, where cond(A) ~ 1/lambda amplifies the fp32 rounding of
                                    the Gram; workspace slots are als_partial_slot_bytes_f64(k) bytes; the
@@ -129,12 +131,12 @@ typedef struct als_row_solve_params {
     int32_t ndual_tail;         /* number of TRAILING tasks that are whole rows (slot < 0) of at most 64 ratings
                                    to be solved in the dual form (n x n instead of k x k system, same
                                    solution); honoured in plain solve calls (no by-product outputs, no
-                                   rhs_extra / diag_extra, bf16x3 Gram).  Pays when the n x n system is much
+                                   rhs_extra / diag_extra, f16x2 Gram).  Pays when the n x n system is much
                                    the smaller one (k > 64: 5x per row at k = 128; at k = 64, n <= 48 it measured
                                    equal to the primal kernel); 0 = never */
     int32_t ndual_mid;          /* number of tasks just BEFORE that tail that are whole rows of 65 ... 96 ratings,
                                    for the dual form at k > 96 (an 80- or 96-size system); 0 = never */
-    int32_t reserved1;
+    int32_t F_scale_ready;      /* != 0: F_scale[0 .. 1] already hold als_factor_scale(F) (several calls on one F) */
     const int64_t* indptr;
     const int32_t* indices;
     const float*   vals;
@@ -163,16 +165,32 @@ typedef struct als_row_solve_params {
     const als_task*     tasks;      int64_t ntasks;
     const als_long_row* long_rows;  int64_t nlong;
     void*          workspace;
-    void*          scratch;             /* nullable: als_row_solve_scratch_bytes(k) bytes, contents irrelevant, must not be
-                                           shared by calls that may run concurrently.  When given (and the call is
-                                           a bf16x3 one without ablation flags) k = 97 ... 128 runs on the
-                                           two-waves-per-row kernel (row_pair.hip), which keeps the running totals of
-                                           rows longer than 512 ratings there; NULL = one wave per row */
+    /* Conditioning-driven precision (solve_dtype "auto"): with cond_limit > 0 every row's condition estimate
+     * kappa = (max_i L_ii / min_i L_ii)^2 <= cond_2(A) is taken from the fp32 factorisation; a row with kappa >
+     * cond_limit (or whose fp32 factorisation breaks down) writes none of its results - its row id is appended to
+     * redo_rows (order irrelevant) and the call then redoes exactly those rows in fp64 (Gram, factorisation,
+     * substitutions: the kernel of ALS_GRAM_F64 on the whole row).  The relative error of an fp32 row is then
+     * bounded by about cond_limit * 3e-7 (the fp32 rounding of its Gram).  f32 / f16x2 modes only. */
+    float          cond_limit;          /* 0 = off */
+    int32_t        byproducts_f64;      /* ALS_GRAM_F64 only, != 0: gram_out, rhs_out, colsum_out, sumr_out, sumr2_out are
+                                           arrays of DOUBLE (same shapes) - for the W-step / item statistics in fp64
+                                           (als_w_params::f64, als_item_stats_f64) - and factor_out an array of double
+                                           (als_gs_sweep_params::factor_f64) */
+    int32_t*       redo_count;          /* device int32[1]; the call resets it; afterwards: number of rows redone */
+    int32_t*       redo_rows;           /* device int32[rows of this orientation] (only the first redo_count are used) */
+    float*         cond_out;            /* nullable [nrows]: kappa of every row solved in fp32 (diagnostics) */
+    float*         F_scale;             /* ALS_GRAM_F16X2: ALS_FSCALE_FLOATS floats of device memory, zero before the FIRST
+                                           use (later calls leave words 2, 3 zero); the call writes {S, 1 / S^2} of F to
+                                           words 0, 1 unless F_scale_ready; must not be shared by concurrent calls */
 } als_row_solve_params;
 
 int als_row_solve(const als_row_solve_params* p, void* stream);
-/* size of als_row_solve_params::scratch for k factors; 0 = not used for this k */
-int64_t als_row_solve_scratch_bytes(int k);
+
+/* Operand scale of the f16x2 Gram for a factor matrix F of `nfloats` floats (a multiple of 4, F 16-byte aligned):
+ * scale[0] = S = 2^j with S max|F| in [2^14, 2^15) (clamped to 2^-60 ... 2^60), scale[1] = 1 / S^2; scale[2 .. 3]
+ * are working words, zero on entry and on exit.  als_row_solve calls this itself unless F_scale_ready. */
+#define ALS_FSCALE_FLOATS 4
+int als_factor_scale(const float* F, int64_t nfloats, float* scale, void* stream);
 
 /* ---------------------------------------------------------------------------
  * als_gs_sweep - one level of the Gauss-Seidel Laplacian sweep.
@@ -197,6 +215,10 @@ typedef struct als_gs_sweep_params {
     const float* sumr2;                  /* [n] from als_row_solve (sumr2_out) */
     const float* lambda_eff;             /* [n] total diagonal shift used in the factor (lambda+1e-10+diag_extra) */
     float* stat_out;                     /* [n][2]: (sum d, sum d^2) with the new V[i], bias[i] */
+    int32_t f64;                         /* != 0: factor, rhs, colsum, sumr, sumr2 are arrays of DOUBLE (als_row_solve with
+                                            ALS_GRAM_F64 and byproducts_f64); neighbour sums, substitutions, bias and
+                                            statistics then run in fp64 (als_gs_sweep / als_gs_sweep_levels only) */
+    int32_t reserved;
 } als_gs_sweep_params;
 
 int als_gs_sweep(const als_gs_sweep_params* p, void* stream);
@@ -257,7 +279,8 @@ typedef struct als_w_params {
     const float* b_new;            /* [n] item bias after the V-step  */
     const float* b_old;            /* [n] item bias before the V-step */
     int32_t D;                     /* total feature columns of X */
-    int32_t reserved;
+    int32_t f64;                   /* != 0: gram, rhs, colsum, H are arrays of double (als_row_solve byproducts_f64) and W
+                                      is the fp64 projection matrix [D][k] (row stride k, storage column order) */
     const float* X;                /* [n][D] all features side by side */
     const int32_t* feat_off;       /* device int32 [nfeat+1] column offsets (phase 0) */
     const float* W;                /* [D][ld] old projections, storage column order (phase 0) */
@@ -294,6 +317,12 @@ int als_item_stats(int k, int ld, int64_t item_begin, int64_t item_end, const fl
                    const float* rhs, const float* colsum, const float* sumr, const float* sumr2,
                    const int64_t* indptr, const float* Z, const float* b_new, const float* b_old,
                    float* stat_out, void* stream);
+
+/* The same from fp64 by-products (als_row_solve with gram_mode ALS_GRAM_F64 and byproducts_f64). */
+int als_item_stats_f64(int k, int ld, int64_t item_begin, int64_t item_end, const double* gram,
+                       const double* rhs, const double* colsum, const double* sumr, const double* sumr2,
+                       const int64_t* indptr, const float* Z, const float* b_new, const float* b_old,
+                       float* stat_out, void* stream);
 
 /* out[0] = sum_i x[2i], out[1] = sum_i x[2i+1] in fp64 (reduction of stat_out).
  * partials: scratch of 2*als_sumsq_partials() doubles. */

@@ -40,6 +40,8 @@ class Golden:
         tr[self.val_pos] = False
         self.train = (rows[tr], cols[tr], vals[tr])
         G, Y = make_features(self.n, c["seed"] + 11)
+        if c.get("dup_cols"):
+            G = np.concatenate([G, G[:, : c["dup_cols"]]], axis=1)
         allf = {"genres": G, "years": Y}
         self.features = {f: allf[f] for f in c["feats"]}
 

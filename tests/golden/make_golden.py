@@ -31,7 +31,7 @@ from tests.synth import make_features, make_folds, make_ratings, to_dense  # noq
 def run_case(name, *, m, n, nnz, seed, k, n_iters, lambda_u, lambda_v,
              pop=None, bu=None, bi=None, update_w_every=5, feats=(), lambda_w=None,
              alpha=0.0, sim=None, tol=None, min_iters=5, empty_users=(),
-             empty_items=(), store_factors=True, sample_rows=0, store_inputs=True):
+             empty_items=(), store_factors=True, sample_rows=0, store_inputs=True, dup_cols=0):
     rows, cols, vals = make_ratings(m, n, nnz, seed, empty_users=empty_users,
                                     empty_items=empty_items)
     folds = make_folds(rows.size, 5, seed + 7)
@@ -40,6 +40,8 @@ def run_case(name, *, m, n, nnz, seed, k, n_iters, lambda_u, lambda_v,
     tr[val_pos] = False
     R_train = to_dense(rows[tr], cols[tr], vals[tr], (m, n))
     G, Y = make_features(n, seed + 11)
+    if dup_cols:        # the first columns once more: an EXACTLY rank-deficient design for the W-step
+        G = np.concatenate([G, G[:, :dup_cols]], axis=1)
     allf = {"genres": G, "years": Y}
     features = {f: allf[f] for f in feats}
     cfg = ALSConfig(
@@ -68,7 +70,7 @@ def run_case(name, *, m, n, nnz, seed, k, n_iters, lambda_u, lambda_v,
             lambda_bu=bu, lambda_bi=bi, update_w_every=update_w_every,
             feats=list(feats), lambda_w=lambda_w, alpha=alpha, sim=sim,
             tol=tol, min_iters=min_iters, empty_users=list(empty_users),
-            empty_items=list(empty_items)))),
+            empty_items=list(empty_items), dup_cols=dup_cols))),
     }
     if store_inputs:      # otherwise the test regenerates them from the seed
         out.update(rows=rows.astype(np.int32), cols=cols.astype(np.int32),
@@ -246,7 +248,22 @@ def main():
     run_case("g11_lam1e-4_k64", m=300, n=200, nnz=6000, seed=113, k=64, n_iters=6,
              lambda_u=1e-4, lambda_v=1e-4, bu=3.0, bi=2.0,
              store_factors=False, sample_rows=64)
-
+    # g12: feature projections WITHOUT lambda_w (missing -> lambda = 0, scripts/als.py:497; the harness's
+    # `no_features`-style configurations, evaluate_models.py:413-417) on RANK-DEFICIENT designs - the reference's
+    # float64 cholesky_solve goes through on the 1e-10 it adds (scripts/als.py:497-500, helpers.py:19-20); a W-step
+    # assembled from fp32 item Grams reports "not positive definite" there:
+    #   dup: two genre columns appear twice (exactly singular A_f, 128 null directions at k = 64);
+    #   k80: k = 80 on 4000 ratings - the configuration DESIGN.md (round 2, section 5) documented as raising.
+    # (A design with far fewer ratings than unknowns - 20 x 64 against 384 - was tried first and is not a usable
+    # fixture: its W is ~10^3 and the fit is chaotic, fp32 storage of U / V alone moves W by 200 %.)
+    run_case("g12_wlam0_dup_k64", m=300, n=200, nnz=6000, seed=122, k=64, n_iters=4,
+             lambda_u=2.0, lambda_v=3.0, bu=0.7, bi=0.9, update_w_every=1,
+             feats=("genres", "years"), lambda_w=None, dup_cols=2,
+             store_factors=False, sample_rows=64)
+    run_case("g12_wlam0_k80", m=300, n=200, nnz=4000, seed=124, k=80, n_iters=3,
+             lambda_u=2.0, lambda_v=3.0, bu=0.7, bi=0.9, update_w_every=1,
+             feats=("genres", "years"), lambda_w=None,
+             store_factors=False, sample_rows=64)
 
 if __name__ == "__main__":
     main()

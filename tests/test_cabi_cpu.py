@@ -29,7 +29,7 @@ def test_header_symbols_are_exported(lib):
 
 def test_host_side_queries(lib):
     from collaborative_filtering_amd import layout
-    assert lib.als_version() == 101
+    assert lib.als_version() == 102
     for k in (1, 15, 16, 17, 50, 64, 128, 160):
         ld = lib.als_padded_k(k)
         assert ld == layout.padded_k(k)
@@ -38,9 +38,6 @@ def test_host_side_queries(lib):
         assert perm == list(layout.perm_of_col(k))
         kb = ld // 16
         assert lib.als_partial_slot_bytes(k) == (kb * (kb + 1) // 2 * 4 + 2 * kb + 2) * 64 * 4
-        # two-waves-per-row kernel: k = 97 ... 128 only; 1024 workgroups x 2 waves x their accumulator blocks
-        want = {7: 1024 * 2 * 14 * 1024, 8: 1024 * 2 * 18 * 1024}.get(kb, 0)
-        assert lib.als_row_solve_scratch_bytes(k) == want
     assert lib.als_padded_k(0) == -2 and lib.als_padded_k(161) == -2
 
 

@@ -224,3 +224,122 @@ def test_forced_collectives_on_one_rank(gs_mode):
     np.testing.assert_array_equal(out["U"], ref.U)
     np.testing.assert_array_equal(out["V"], ref.V)
     np.testing.assert_array_equal(out["rmse"], ref.history["train_rmse"])
+
+
+def test_four_rank_shards_are_balanced_by_predicted_cost():
+    """Shards are cut by ratings + c(k) * rows (layout.shard_bounds_nnz with row_cost): on the skewed input the
+    predicted per-rank cost stays within 10 % of the mean (up to the granularity of one row), while shards balanced
+    by ratings alone would be far off."""
+    from collaborative_filtering_amd import layout
+    rng = np.random.default_rng(3)
+    lens = np.sort((rng.pareto(1.2, 50_000) * 20).astype(np.int64))[::-1]          # heavy rows first
+    ptr = np.concatenate([[0], np.cumsum(lens)])
+    c = layout.row_cost_weight(64)
+    for world in (2, 4, 8):
+        bounds, chunks = layout.shard_bounds_nnz(ptr, world, 2, c)
+        assert bounds[0][0] == 0 and bounds[-1][1] == lens.size
+        assert all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
+        cost = layout.shard_costs(ptr, bounds, c)
+        assert cost.max() <= 1.10 * cost.mean() + lens.max() + c, (world, cost)
+        for (b, e), ch in zip(bounds, chunks):                                      # sub-ranges tile the shard
+            assert ch[0][0] == b and ch[-1][1] == e and ch[0][1] == ch[1][0]
+            cc = layout.shard_costs(ptr, ch, c)
+            assert cc.max() <= 1.10 * cc.mean() + lens.max() + c
+        by_ratings, _ = layout.shard_bounds_nnz(ptr, world)
+        assert layout.shard_costs(ptr, by_ratings, c).max() > 1.4 * cost.mean()      # what the weight repairs
+    (r, c2, v), _, _ = _skewed_problem()
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=120))])
+    b4, _ = layout.shard_bounds_nnz(ptr, 4, 1, layout.row_cost_weight(6))
+    cost = layout.shard_costs(ptr, b4, layout.row_cost_weight(6))
+    assert cost.max() <= 1.10 * cost.mean() + np.diff(ptr).max() + layout.row_cost_weight(6)
+
+
+def _status_worker(rank, world, port, outdir):
+    """Rank 1's sweep raises the error word once (as a timed-out dependency wait would); the status words are
+    reduced over the group, so BOTH ranks must see SweepNotResident in the same iteration and refit together."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import collaborative_filtering_amd.als as A
+        from tests.common import Golden
+        from tests.cpu_backend import NumpyBackend
+        from tests.test_gpu_parity import _model_for
+
+        class FlakyDataflow(NumpyBackend):
+            """Stand-in with a `gs_dataflow` entry (level by level underneath)."""
+            fired = 0
+
+            def gs_dataflow(self, *, items, S_idx_wait, publish, err, nondep=None, **kw):
+                sched = self.engine().sched
+                for lv in range(len(sched.offsets) - 1):
+                    self.gs_level(items=items[sched.offsets[lv]:sched.offsets[lv + 1]], **kw)
+                if rank == 1 and FlakyDataflow.fired == 0:
+                    err.fill_(1)
+                    FlakyDataflow.fired = 1
+
+        g = Golden("g5_graph_a0.5")
+        r, c, v = g.train
+        be = FlakyDataflow()
+        model = _model_for(g, device="cpu", backend=be, process_group="world")
+        be.engine = lambda: model._eng
+        raised = []
+        orig_init = A._Engine.__init__
+
+        def counting_init(self, *a, **kw):
+            raised.append(1)
+            orig_init(self, *a, **kw)
+        A._Engine.__init__ = counting_init
+        model.fit_coo(r, c, v, (g.m, g.n), features=g.features or None, tol=g.cfg["tol"], min_iters=g.cfg["min_iters"],
+                      verbose=0)
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), V=model.V, U=model.U, engines=len(raised),
+                 dataflow=int(model._eng.gs_dataflow), rmse=np.asarray(model.history["train_rmse"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sweep_error_on_one_rank_makes_every_rank_refit():
+    g, ref = _single("g5_graph_a0.5")
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_status_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        outs = [np.load(os.path.join(d, f"rank{r}.npz")) for r in range(2)]
+    for o in outs:
+        assert int(o["engines"]) == 2 and int(o["dataflow"]) == 0        # both ranks built a second engine
+        np.testing.assert_array_equal(o["V"], ref.V)
+        np.testing.assert_array_equal(o["U"], ref.U)
+        assert len(o["rmse"]) == len(ref.history["train_rmse"])            # the failed run left no history behind
+
+
+def _bench_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import json
+
+    import bench
+    from tests.cpu_backend import NumpyBackend
+    out = bench.main(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--size", "tiny", "--no-cpu-baseline",
+                      "--dist-backend", "gloo"], backend=NumpyBackend(), device="cpu")
+    if rank == 0:
+        with open(os.path.join(outdir, f"bench_w{world}.json"), "w") as fh:
+            json.dump(out, fh)
+    else:
+        assert out is None
+
+
+def test_bench_torchrun_path_end_to_end_on_four_cpu_ranks():
+    """`bench.py`'s own code path as the driver launches it for N > 1 - rank 0 generates and broadcasts, sharded
+    engine with the two-chunk U-step and its overlapped all-gathers, exact shard-ordered sweep, barrier + MAX over
+    ranks, one JSON line on rank 0 - at `tiny` size on 4 CPU ranks over gloo (numpy stand-in for the kernels): an
+    argument or shape bug surfaces here, not on the 8-GPU node.  The history equals the one-rank run bitwise."""
+    import json
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_bench_worker, args=(4, _free_port(), d), nprocs=4, join=True)
+        mp.spawn(_bench_worker, args=(1, _free_port(), d), nprocs=1, join=True)
+        o4 = json.load(open(os.path.join(d, "bench_w4.json")))
+        o1 = json.load(open(os.path.join(d, "bench_w1.json")))
+    assert o4["n_gpus"] == 4 and o4["steps"] == 2 and o4["value"] > 0 and o4["scaling"] == "strong"
+    assert o4["config"]["gs_mode"] == "exact" and o4["config"]["gs_levels"] > 0 and "scaling_cap" in o4["config"]
+    assert o4["metric"].startswith("ratings/sec") and o4["unit"] == "ratings/s"
+    assert np.all(np.isfinite(o4["train_rmse"])) and o4["train_rmse"] == o1["train_rmse"]

@@ -7,9 +7,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _env(gram="bf16x3"):
+def _env(gram="f16x2"):
     solve_dtype = "float64" if gram == "f64" else "float32"      # "f64": ALS_GRAM_F64 (row_solve_f64.hip)
-    gram = "bf16x3" if gram == "f64" else gram
+    gram = "f16x2" if gram == "f64" else gram
     import torch
     if not torch.cuda.is_available():
         pytest.fail("GPU tests selected (-m gpu) but no ROCm device is visible")
@@ -36,7 +36,7 @@ def _pad(A, ld, extra_rows=0):
     return out
 
 
-@pytest.mark.parametrize("gram", ["bf16x3", "f32", "f64"])
+@pytest.mark.parametrize("gram", ["f16x2", "f32", "f64"])
 @pytest.mark.parametrize("k", [1, 16, 32, 50, 64, 80, 96, 112, 128, 160])
 def test_row_solve_against_numpy(k, gram):
     torch, layout, side_dev, tasks_dev, be, dev = _env(gram)
@@ -105,15 +105,6 @@ def test_row_solve_against_numpy(k, gram):
                                    atol=ga * max(np.max(np.abs(ref)), 1e-6))
 
 
-@pytest.mark.parametrize("k", [100, 112, 120, 128])
-def test_two_waves_per_row_kernel_against_numpy(k, monkeypatch):
-    """row_pair.hip (opt-in, ALS_ROW_PAIR=1): same rows, same checks as the one-wave kernel - rows of 1 ... 8200
-    ratings incl. the split path and the running totals of rows longer than 512 ratings, Gram by-product,
-    rhs_extra / diag_extra, padded columns (k = 100: KB = 7, k = 120: KB = 8)."""
-    monkeypatch.setenv("ALS_ROW_PAIR", "1")
-    test_row_solve_against_numpy(k, "bf16x3")
-
-
 @pytest.mark.parametrize("k", [16, 50, 64, 128])
 def test_row_solve_f64_small_lambda(k):
     """ALS_GRAM_F64 at lambda = 1e-4 with rows shorter than k (cond ~ 1/lambda, where the fp32 kernels lose the
@@ -167,7 +158,7 @@ def test_row_solve_f64_small_lambda(k):
         assert abs(st[r, 1] - (d * d).sum()) <= 1e-5 * max(1e-3, (d * d).sum()) + 1e-9 * (rho * rho).sum()
 
 
-@pytest.mark.parametrize("gram", ["bf16x3", "f64"])
+@pytest.mark.parametrize("gram", ["f16x2", "f64"])
 @pytest.mark.parametrize("k", [16, 64, 80, 96, 128, 160])
 def test_factor_mode_and_gs_level(k, gram):
     """factor-only als_row_solve + als_gs_sweep on one level == direct solve with the graph term."""
@@ -237,12 +228,6 @@ def test_factor_mode_and_gs_level(k, gram):
         np.testing.assert_allclose(Vn[i, :k], x, rtol=2e-3, atol=2e-4 * max(np.max(np.abs(x)), 1e-6))
         bref = np.sum(vals - Fr @ x - mu - b_other[idx]) / ((hi - lo) + lam_b + 1e-10)
         assert abs(bn[i] - bref) <= 2e-4 * max(1.0, abs(bref))
-
-
-@pytest.mark.parametrize("k", [112, 128])
-def test_two_waves_per_row_kernel_factor_mode(k, monkeypatch):
-    monkeypatch.setenv("ALS_ROW_PAIR", "1")
-    test_factor_mode_and_gs_level(k, "bf16x3")
 
 
 @pytest.mark.parametrize("k", [1, 16, 50, 64, 96, 128, 160])
@@ -363,7 +348,7 @@ def test_dual_form_short_rows_against_numpy_and_the_primal_kernel(k):
     dual form (n x n system); longer rows and split rows stay primal.  Every row against numpy fp64, the
     closed-form bias and residual sums against their definitions, and the dual rows against the primal kernel
     (ndual_tail = 0) on the same input."""
-    torch, layout, side_dev, tasks_dev, be, dev = _env("bf16x3")
+    torch, layout, side_dev, tasks_dev, be, dev = _env("f16x2")
     ncols = 5000
     lens = [1, 2, 0, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 100, 4097 + 40, 64, 7, 300, 66, 79, 80, 81, 95,
             96, 97]
@@ -438,7 +423,7 @@ def test_dual_form_short_rows_against_numpy_and_the_primal_kernel(k):
 def test_dual_classes_are_ignored_by_calls_with_byproducts():
     """Regression: a factor-only call (no X_out) whose task list carries dual classes (here: only the
     65...96 class, no short rows) must keep every row primal - the dual kernels write X_out."""
-    torch, layout, side_dev, tasks_dev, be, dev = _env("bf16x3")
+    torch, layout, side_dev, tasks_dev, be, dev = _env("f16x2")
     k, ncols = 128, 3000
     lens = [70, 80, 96, 200, 90]
     nrows = len(lens)
@@ -470,7 +455,7 @@ def test_dual_classes_are_ignored_by_calls_with_byproducts():
 def test_dual_and_primal_agree_on_random_shapes():
     """Seeded sweep over ranks and row-length mixes: the dual classes (<= 64 ratings; 65...96 above k = 96)
     and the primal kernel must agree row by row within the fp32 tolerance, including bias and residual sums."""
-    torch, layout, side_dev, tasks_dev, be, dev = _env("bf16x3")
+    torch, layout, side_dev, tasks_dev, be, dev = _env("f16x2")
     rng = np.random.default_rng(2024)
     f32 = torch.float32
     for trial in range(12):
@@ -509,47 +494,3 @@ def test_dual_and_primal_agree_on_random_shapes():
         np.testing.assert_allclose(Xd, Xp, rtol=0, atol=5e-4 * scale, err_msg=f"trial {trial} k {k}")
         np.testing.assert_allclose(bd, bp, rtol=0, atol=3e-4)
         np.testing.assert_allclose(sdl, sp, rtol=2e-3, atol=2e-3)
-
-
-@pytest.mark.parametrize("k", [105, 128])
-def test_two_waves_per_row_kernel_agrees_with_one_wave(k):
-    """Same plain solve (incl. in-place bias and the closed-form residual sums) through row_pair.hip and through
-    the one-wave kernel: rows of 1 ... 1500 ratings, all primal."""
-    torch, layout, side_dev, tasks_dev, be, dev = _env("bf16x3")
-    rng = np.random.default_rng(77 + k)
-    f32 = torch.float32
-    ncols = 4000
-    lens = [1, 3, 17, 64, 65, 100, 128, 129, 300, 511, 512, 513, 1024, 1500] + [int(x) for x in rng.integers(60, 400, 50)]
-    nrows = len(lens)
-    side = _random_side(layout, nrows, ncols, lens, seed=k)
-    ld = layout.padded_k(k)
-    t = layout.build_row_tasks(side.indptr)                  # no dual classes
-    Fd = torch.from_numpy(_pad(rng.normal(scale=0.3, size=(ncols, k)), ld, 1)).to(dev)
-    b_self = torch.from_numpy(rng.normal(scale=0.2, size=nrows).astype(np.float32)).to(dev)
-    b_other = torch.from_numpy(rng.normal(scale=0.2, size=ncols).astype(np.float32)).to(dev)
-    sd, td = side_dev(side, dev), tasks_dev(t, dev)
-
-    def run(pair):
-        be.row_pair = pair
-        X = torch.zeros(nrows, ld, dtype=f32, device=dev)
-        bias = b_self.clone()
-        stat = torch.zeros(nrows, 2, dtype=f32, device=dev)
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
-        be.row_solve(k=k, ld=ld, side=sd, F=Fd, zero_row=ncols, bias_self=bias, bias_other=b_other,
-                     mu=torch.tensor([3.1], dtype=torch.float64, device=dev), lam=0.7, lam_row=None, lam_b=1.3,
-                     lam_b_row=None, rhs_extra=None, diag_extra=None, X_out=X, bias_out=bias, gram_out=None,
-                     factor_out=None, rhs_out=None, colsum_out=None, sumr_out=None, status=status, tasks=td,
-                     workspace=None, stat_out=stat)
-        torch.cuda.synchronize()
-        assert int(status.item()) == 0
-        return X.cpu().numpy(), bias.cpu().numpy(), stat.cpu().numpy()
-
-    X1, b1, s1 = run(False)
-    X2, b2, s2 = run(True)
-    X3, b3, s3 = run(True)
-    assert np.array_equal(X2, X3) and np.array_equal(b2, b3) and np.array_equal(s2, s3)      # reproducible
-    assert np.all(X2[:, k:] == 0.0)
-    scale = max(float(np.abs(X1).max()), 1e-6)
-    np.testing.assert_allclose(X2, X1, rtol=0, atol=2e-5 * scale)
-    np.testing.assert_allclose(b2, b1, rtol=0, atol=2e-5)
-    np.testing.assert_allclose(s2, s1, rtol=1e-3, atol=1e-3)

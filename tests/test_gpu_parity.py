@@ -49,8 +49,10 @@ def _model_for(g: Golden, **kw):
 
 
 TOL = dict(hist=2e-6, norms=2e-6, test_rmse=1e-6, f_rtol=1e-4, f_atol=5e-5, bias=5e-6, mu=1e-6, pred=3e-4)
-# fp32 solve only; keyed by fixture.  None = outside the 1e-4 budget in fp32 (documented, not asserted).
-TOL_OVERRIDES = {
+# solve_dtype="float32" ONLY (every row in fp32 whatever its conditioning); keyed by fixture.  None = outside the 1e-4
+# budget in fp32 (documented, not asserted).  The default (solve_dtype="auto") has no overrides: rows whose condition
+# estimate exceeds the limit are redone in fp64 by the same call.
+TOL_FP32_ONLY = {
     "g11_lam1e-2_k64": dict(hist=1e-4, norms=1e-3, test_rmse=1e-4, f_rtol=0.0, f_atol=1e-2, bias=2e-4, mu=1e-6, pred=2e-2),
     "g11_lam1e-4_k64": None,
 }
@@ -60,6 +62,16 @@ TOL_OVERRIDES = {
 # Laplacian, the fp32 item Grams of the W-step and the fp32 triangular solves of the sweep).  Observed over all
 # fixtures: history <= 7e-9, fold test RMSE <= 9e-9, biases <= 6e-8, mu <= 7e-9, factors <= 5.3e-6 of max|ref|.
 TOL64 = dict(hist=1e-7, norms=2e-6, test_rmse=1e-7, f_rtol=1e-4, f_atol=5e-5, bias=1e-6, mu=1e-7, pred=5e-5)
+# g12_wlam0_k80 (lambda_w = 0, k = 80 on 4000 ratings: |W| ~ 80) is ill-conditioned as a PROBLEM: rounding U, V, b to
+# fp32 between the half-steps of the float64 oracle - the product's storage type, nothing else changed - already moves
+# its predictions by 2.6e-5 and its fold RMSE by 1.3e-7 (the other fixtures: 3e-6 / 8e-9).  Its prediction / fold-RMSE
+# bands are therefore ~10x that floor, as is the factor / W band (floor 8.5e-6 of max|W|, observed 8.6e-5 with the
+# f32-MFMA Gram); history and biases stay in the common bands.
+TOL_ILL_POSED = {"g12_wlam0_k80": dict(test_rmse=1e-5, pred=3e-4, f_atol=2e-4)}
+
+
+def _tol_for(name, base):
+    return dict(base, **TOL_ILL_POSED.get(name, {}))
 
 
 def _close(got, ref, rtol=TOL["f_rtol"], atol_rel=TOL["f_atol"], what=""):
@@ -93,22 +105,35 @@ def _check_against_fixture(model, g: Golden, tol):
     assert abs(rmse - float(d["test_rmse"][0])) <= tol["test_rmse"]
 
 
-@pytest.mark.parametrize("gram", ["bf16x3", "f32"])
+@pytest.mark.parametrize("gram", ["f16x2", "f32"])
 @pytest.mark.parametrize("name", golden_names())
 def test_fit_matches_reference_fixture(name, gram):
-    """Both Gram modes of K1 (f32 MFMA; exact 3-way bf16 split on the bf16 matrix cores) are held
-    to the same tolerances against the float64 reference."""
+    """The DEFAULT path (solve_dtype="auto") in both Gram modes of K1 (2-way fp16 split on the fp16 matrix cores;
+    f32 MFMA) is held to the same tight tolerances against the float64 reference on EVERY fixture - including the
+    lambda = 1e-2 / 1e-4 corner of the tuner's search space (scripts/tune_params.py:100-101), whose ill-conditioned
+    rows the call redoes in fp64, and the rank-deficient lambda_w = 0 designs."""
     _cuda()
     g = Golden(name)
-    tol = TOL_OVERRIDES.get(name, TOL)
     model = _model_for(g, gram=gram)
     r, c, v = g.train
     model.fit_coo(r, c, v, (g.m, g.n), features=g.features or None, tol=g.cfg["tol"],
                   min_iters=g.cfg["min_iters"], verbose=0)
+    _check_against_fixture(model, g, _tol_for(name, TOL))
+
+
+@pytest.mark.parametrize("name", sorted(TOL_FP32_ONLY))
+def test_fp32_only_mode_at_small_lambda_is_what_the_docs_say(name):
+    """solve_dtype="float32" (no fp64 redo): lambda = 1e-2 stays inside the 1e-4 RMSE budget but outside the tight
+    band; lambda = 1e-4 leaves the budget (observed 1e-2) - the fit must still run and stay finite.  This is why
+    "auto" is the default."""
+    _cuda()
+    g = Golden(name)
+    model = _model_for(g, solve_dtype="float32")
+    r, c, v = g.train
+    model.fit_coo(r, c, v, (g.m, g.n), features=g.features or None, tol=g.cfg["tol"],
+                  min_iters=g.cfg["min_iters"], verbose=0)
+    tol = TOL_FP32_ONLY[name]
     if tol is None:
-        # lambda = 1e-4, rows shorter than k: cond ~ 1/lambda amplifies the fp32 rounding of the Gram beyond the
-        # 1e-4 RMSE budget (observed 1e-2).  The fit must still run and stay finite; solve_dtype="float64" is
-        # the mode that matches the reference here (test_fit_float64_matches_reference_fixture).
         assert np.all(np.isfinite(model.U)) and np.all(np.isfinite(model.V))
         assert len(model.history["train_rmse"]) == len(g.d["hist_train_rmse"])
         return
@@ -125,7 +150,7 @@ def test_fit_float64_matches_reference_fixture(name):
     r, c, v = g.train
     model.fit_coo(r, c, v, (g.m, g.n), features=g.features or None, tol=g.cfg["tol"],
                   min_iters=g.cfg["min_iters"], verbose=0)
-    _check_against_fixture(model, g, TOL64)
+    _check_against_fixture(model, g, _tol_for(name, TOL64))
 
 
 def test_fit_falls_back_to_level_sweeps_when_the_dataflow_launch_gives_up(monkeypatch):
@@ -144,10 +169,69 @@ def test_fit_falls_back_to_level_sweeps_when_the_dataflow_launch_gives_up(monkey
             self.gs_err.fill_(1)            # what the kernel does on a timed-out wait
             hits["n"] += 1
     monkeypatch.setattr(A._Engine, "_gs_sweep", flaky)
+    monkeypatch.setattr(A, "_DATAFLOW_GAVE_UP", set())      # (the per-device memory of the fallback: restored after the test)
     model = _model_for(g)
     model.fit_coo(r, c, v, (g.m, g.n), features=g.features, tol=None, verbose=0)
     assert hits["n"] == 1 and not model._eng.gs_dataflow and not model._dataflow_sweep
     _check_against_fixture(model, g, TOL)
+    # the decision is remembered for the device: a NEW model (what a sweep driver makes per fit) starts with the
+    # per-level launches instead of paying a failed attempt again
+    assert A._DATAFLOW_GAVE_UP
+    again = _model_for(g).fit_coo(r, c, v, (g.m, g.n), features=g.features, tol=None, verbose=0)
+    assert hits["n"] == 1 and not again._eng.gs_dataflow
+    _check_against_fixture(again, g, TOL)
+
+
+def test_refit_after_a_failed_sweep_leaves_no_history_of_the_failed_run(monkeypatch):
+    """Second `fit` of one model (history appends, scripts/als.py:168-176 quirk) whose first attempt at the sweep
+    gives up: the failed run must not have appended anything - the history is first fit + the refit, nothing more."""
+    _cuda()
+    import collaborative_filtering_amd.als as A
+    g = Golden("g5_graph_a0.5")
+    r, c, v = g.train
+    monkeypatch.setattr(A, "_DATAFLOW_GAVE_UP", set())
+    model = _model_for(g)
+    model.fit_coo(r, c, v, (g.m, g.n), features=g.features, tol=None, verbose=0)
+    first = list(model.history["train_rmse"])
+    orig = A._Engine._gs_sweep
+    hits = {"n": 0}
+
+    def flaky(self):
+        orig(self)
+        if self.gs_dataflow and hits["n"] == 0:
+            self.gs_err.fill_(1)
+            hits["n"] += 1
+    monkeypatch.setattr(A._Engine, "_gs_sweep", flaky)
+    model.fit_coo(r, c, v, (g.m, g.n), features=g.features, tol=None, verbose=0)
+    assert hits["n"] == 1
+    for key in ("train_rmse", "U_norm", "V_norm", "bu_norm", "bi_norm"):
+        assert len(model.history[key]) == 2 * len(first), key
+    assert model.history["train_rmse"][: len(first)] == first
+    # (the refit sweeps level by level: same arithmetic per item, the neighbour sums in another order)
+    np.testing.assert_allclose(model.history["train_rmse"][len(first):], first, rtol=0, atol=1e-7)
+
+
+def test_predict_composes_z_from_the_features_it_is_given():
+    """scripts/als.py:568-572: predict builds Z from whatever features are passed.  In-place edits of the fit's
+    arrays, or different arrays, must show in the predictions (round 2 short-cut on object identity: stale Z)."""
+    _cuda()
+    g = Golden("g4_feat_uw1")
+    r, c, v = g.train
+    feats = {f: np.array(X, copy=True) for f, X in g.features.items()}
+    model = _model_for(g).fit_coo(r, c, v, (g.m, g.n), features=feats, tol=None, verbose=0)
+    idx = g.val_flat()
+    base = model.predict_at(idx, feats)
+    name = next(iter(feats))
+    feats[name] *= 0.5                                      # in place: same object, new contents
+    edited = model.predict_at(idx, feats)
+    fresh = model.predict_at(idx, {f: np.array(X, copy=True) for f, X in feats.items()})
+    np.testing.assert_array_equal(edited, fresh)
+    assert np.max(np.abs(edited - base)) > 1e-4
+    # expected: U (V + sum_f X_f W_f)^T + mu + b_u + b_i with the edited X
+    Z = model.V + sum(np.asarray(feats[f], dtype=np.float64) @ model.W[f] for f in feats)
+    u, i = np.divmod(idx, g.n)
+    want = np.einsum("tk,tk->t", model.U[u], Z[i]) + model.mu + model.b_u[u] + model.b_i[i]
+    np.testing.assert_allclose(edited, want, atol=2e-5, rtol=0)
 
 
 def test_dense_entry_and_dense_predict():

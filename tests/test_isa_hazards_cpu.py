@@ -83,6 +83,113 @@ def _check(text):
     return ndpp
 
 
+MFMA16_WAIT = 11      # wait states between an 8-pass matrix instruction and a vector / LDS / memory read of its result
+
+
+def _parse(text):
+    """[(function, [(address, instruction)])] of one disassembly."""
+    funcs, cur = [], None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+        if m:
+            cur = []
+            funcs.append((m.group(1), cur))
+            continue
+        if cur is None or not line.startswith("\t"):
+            continue
+        ins = line.split("//")[0].strip()
+        am = re.search(r"//\s*([0-9A-Fa-f]+):", line)
+        if ins and am:
+            cur.append((int(am.group(1), 16), ins))
+    return funcs
+
+
+def _reads(ins):
+    """VGPRs an instruction (not an MFMA) reads: every register operand but the destination; all of them for stores."""
+    parts = ins.split(None, 1)
+    if len(parts) < 2:
+        return set()
+    name, ops = parts[0], [o.split()[0] if o.strip() else "" for o in parts[1].split(",")]
+    store = name.startswith(("ds_write", "ds_store", "global_store", "buffer_store", "flat_store", "scratch_store",
+                             "global_atomic"))
+    out = set()
+    for j, o in enumerate(ops):
+        if j == 0 and not store and not name.startswith(("v_cmp", "s_")):
+            continue
+        out |= _vgprs(o)
+    return out
+
+
+def _check_mfma_results(text, opcode="v_mfma_f32_16x16x32_f16", need=MFMA16_WAIT):
+    """Every result of `opcode` must be `need` wait states old before anything but another MFMA reads it, on the
+    fall-through path and on the taken side of every forward branch inside the window.  Returns the number of such
+    matrix instructions seen."""
+    count = 0
+    for fn, code in _parse(text):
+        index = {a: i for i, (a, _) in enumerate(code)}
+
+        def walk(i, dst, waited, depth=0):
+            while i < len(code) and waited < need:
+                a, ins = code[i]
+                if ins.startswith("v_mfma"):
+                    ops = ins.split(None, 1)[1].split(",")
+                    if _vgprs(ops[0]) >= dst:
+                        return                         # overwritten by a later matrix instruction: its own check
+                elif ins.startswith(("s_endpgm", "s_branch", "s_setpc")):
+                    return
+                else:
+                    assert not (_reads(ins) & dst), (f"{fn}: `{ins}` reads a {opcode} result after {waited} wait "
+                                                     f"states (needs {need})")
+                    if not ins.startswith(("s_", "ds_write", "ds_store", "global_store", "buffer_store", "scratch_store")):
+                        dst = dst - _vgprs(ins.split(None, 1)[1].split(",")[0].split()[0]) if " " in ins else dst
+                        if not dst:
+                            return                     # every register of the result has been redefined
+                    m = re.match(r"s_cbranch_\w+ (\d+)", ins)
+                    if m and depth < 4 and int(m.group(1)) < 0x8000:
+                        nxt = code[i + 1][0] if i + 1 < len(code) else None
+                        tgt = None if nxt is None else index.get(nxt + 4 * int(m.group(1)))
+                        if tgt is not None:
+                            walk(tgt, dst, waited + 1, depth + 1)
+                m = re.match(r"s_nop (\d+)", ins)
+                waited += int(m.group(1)) + 1 if m else 1
+                i += 1
+
+        for i, (a, ins) in enumerate(code):
+            if ins.startswith(opcode):
+                count += 1
+                walk(i + 1, _vgprs(ins.split(None, 1)[1].split(",")[0]), 0)
+    return count
+
+
+def test_mfma_result_checker_on_synthetic_code():
+    mf = "\tv_mfma_f32_16x16x32_f16 v[2:5], v[10:13], v[14:17], v[2:5] // 000000001000: 0 0\n"
+    rd = "\tv_pk_mul_f32 v[4:5], v[4:5], v[20:21] // 00000000100C: 0 0\n"
+    ok = "0000000000001000 <f>:\n" + mf + "\ts_nop 15 // 000000001008: 0\n" + rd
+    assert _check_mfma_results(ok) == 1
+    chain = "0000000000001000 <f>:\n" + mf + "\tv_mfma_f32_16x16x32_f16 v[2:5], v[10:13], v[14:17], v[2:5] // 000000001008: 0 0\n"
+    assert _check_mfma_results(chain) == 2                 # accumulate chains are not reads in this sense
+    with pytest.raises(AssertionError):
+        _check_mfma_results("0000000000001000 <f>:\n" + mf + "\tv_mov_b32_e32 v9, v8 // 000000001008: 0\n" + rd)
+    # the read sits on the TAKEN side of a forward branch that skips the padding
+    br = ("0000000000001000 <f>:\n" + mf + "\ts_cbranch_scc1 2 // 000000001008: 0\n\ts_nop 15 // 00000000100C: 0\n"
+          "\ts_nop 3 // 000000001010: 0\n\tv_pk_mul_f32 v[4:5], v[4:5], v[20:21] // 000000001014: 0 0\n")
+    with pytest.raises(AssertionError):
+        _check_mfma_results(br)
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump of the ROCm image not present")
+def test_f16_mfma_results_are_not_read_early(tmp_path):
+    """hipcc under-padded the matrix-result -> vector-read hazard of v_mfma_f32_16x16x32_f16 on one path of the dual
+    row-solve kernel (wrong rows at random, round 3); row_common.hpp::mfma_results_settle spells the wait out.
+    This walks the built code object and fails if any such result is read within the hazard window."""
+    if not os.path.exists(LIB):
+        import __graft_entry__ as ge
+        ge.build()
+    texts = _disassemble(tmp_path)
+    n = sum(_check_mfma_results(t) for t in texts)
+    assert n > 1000, f"expected the Gram's fp16 matrix instructions in the code object, found {n}"
+
+
 def test_checker_sees_a_hazard_and_accepts_the_ordered_form():
     dpp = "\tv_fmac_f32_dpp v5, v45, v46 row_newbcast:3 row_mask:0xf bank_mask:0xf// 0000: 0 0\n"
     ok = "f:\n\tv_mul_f32_e32 v45, v32, v46  // 0\n\ts_nop 1  // 0\n\tv_xor_b32_e32 v46, 0x80000000, v4 // 0\n" + dpp
