@@ -391,7 +391,7 @@ __device__ __forceinline__ void chol_panels(RowAcc<KB>& A, Chol<KB>& S, float* _
 // ---------------------------------------------------------------------------
 template <int KB>
 __device__ __forceinline__ bool row_needs_f64(const Chol<KB>& S, const als_row_solve_params& P, int row, bool spd,
-                                              int lane) {
+                                              float mean_eig, float short_row_bound, int lane) {
     float dmx = 0.f, dmn = 0.f;          // max of 1 / L_ii and of L_ii over the lane's rows
 #pragma unroll
     for (int rr = 0; rr < KCfg<KB>::NR; ++rr) {
@@ -403,11 +403,34 @@ __device__ __forceinline__ bool row_needs_f64(const Chol<KB>& S, const als_row_s
     dmx = wave_max_nonneg(fmaxf(dmx, 0.f));
     dmn = wave_max_nonneg(fmaxf(dmn, 0.f));
     const float r = dmx * dmn;
-    const float kappa = spd ? r * r : __builtin_inff();
+    // two lower bounds of cond_2(A): the pivot ratio, and (mean of the non-trivial eigenvalues) / (smallest pivot) -
+    // lambda_max >= trace(G) / rank(G) + lambda.  The second one sees what the first misses: a row with a handful
+    // of ratings has a few eigenvalues of the size of |f|^2 and k - n equal to lambda, while its largest PIVOT is
+    // only max_c f_c^2 + lambda (at lambda = 1e-4: estimate 100 against a true 6400).
+    // Both use the smallest PIVOT for lambda_min, which it can exceed by a factor of up to k.  For rows of fewer than
+    // 4 k ratings - where the Gram's own smallest eigenvalues are zero or unreliable - lambda_min is therefore taken
+    // as the regulariser itself (short_row_bound = mean eigenvalue / lambda, 0 for longer rows): pessimistic by at
+    // most (lambda + sigma_min(G)) / lambda, and what makes the lambda = 1e-4 rows of k ... 4 k ratings go to fp64.
+    const float kappa = spd ? fmaxf(fmaxf(r * r, mean_eig * dmx * dmx), short_row_bound) : __builtin_inff();
     if (P.cond_out && lane == 0) P.cond_out[row] = kappa;
     const bool redo = !(kappa <= P.cond_limit);
     if (redo && lane == 0) P.redo_rows[atomicAdd(P.redo_count, 1)] = row;
     return redo;
+}
+
+// trace of the accumulated Gram (before the regulariser goes on): its diagonal sits in the lanes q == c >> 2,
+// register c & 3 of every diagonal block
+template <int KB>
+__device__ __forceinline__ float gram_trace(const RowAcc<KB>& A, int lane) {
+    const int c = lane & 15, q = lane >> 4;
+    float t = 0.f;
+#pragma unroll
+    for (int J = 0; J < KB; ++J) {
+        const f32x4 a = A.acc[blk_idx(J, J)];
+        const float lo = (c & 1) ? a[1] : a[0], hi = (c & 1) ? a[3] : a[2];
+        t += (c & 2) ? hi : lo;
+    }
+    return wave_sum((q == (c >> 2)) ? t : 0.f);
 }
 
 // ---------------------------------------------------------------------------
@@ -481,6 +504,12 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
     // regulariser on the diagonal (C/D layout: diagonal where 4q + r == c); padded columns get 1
     const float lam = (P.lambda_row ? P.lambda_row[row] : P.lambda_scalar) + ALS_EPS
                     + (P.diag_extra ? P.diag_extra[row] : 0.f);
+    float mean_eig = 0.f, short_row_bound = 0.f;       // (condition estimate of solve_dtype "auto" only)
+    if (P.cond_limit > 0.f) {
+        const int64_t nrat = P.indptr[row + 1] - P.indptr[row];
+        mean_eig = gram_trace<KB>(A, lane) / fmaxf((float)min((int64_t)P.k, nrat), 1.f) + lam;
+        short_row_bound = (nrat < 4 * (int64_t)P.k) ? mean_eig / lam : 0.f;
+    }
 #pragma unroll
     for (int J = 0; J < KB; ++J) {
         const float dv = (perm_to_col<KB>(16 * J + c) < P.k) ? lam : 1.0f;
@@ -492,7 +521,7 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
         chol_panels<KB, 0, false>(A, S, Ls, lane);
         const bool spd = chol_spd<KB>(S, lane);
         if (P.cond_limit > 0.f) {
-            if (row_needs_f64<KB>(S, P, row, spd, lane)) return;
+            if (row_needs_f64<KB>(S, P, row, spd, mean_eig, short_row_bound, lane)) return;
         } else if (!spd && lane == 0) atomicMax(P.status, row + 1);
         // symmetric completion of L with 1/L_ii on the diagonal, perm space:
         // M[p][i] = L[i][p] (p < i), L[p][i] (p > i)
@@ -528,7 +557,7 @@ __device__ __forceinline__ void finish_row(RowAcc<KB>& A, const als_row_solve_pa
         chol_panels<KB, 0, true>(A, S, Ls, lane);
         const bool spd = chol_spd<KB>(S, lane);
         if (P.cond_limit > 0.f) {
-            if (row_needs_f64<KB>(S, P, row, spd, lane)) return;
+            if (row_needs_f64<KB>(S, P, row, spd, mean_eig, short_row_bound, lane)) return;
         } else if (!spd && lane == 0) atomicMax(P.status, row + 1);
     }
     float x[NR];
@@ -711,6 +740,7 @@ __device__ __forceinline__ void row_dual(const als_row_solve_params& P, int row,
     }
     // + l I on the rows in use, identity on the padding rows (their rows / columns of K are zero)
     const float lam = (P.lambda_row ? P.lambda_row[row] : P.lambda_scalar) + ALS_EPS;
+    const float dual_mean_eig = (P.cond_limit > 0.f) ? gram_trace<NB>(A, lane) / (float)max(min(len, P.k), 1) + lam : 0.f;
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
         const float dv = (16 * J + c < len) ? lam : 1.0f;
@@ -725,7 +755,7 @@ __device__ __forceinline__ void row_dual(const als_row_solve_params& P, int row,
         // (F F^T + l I and F^T F + l I share their spectrum up to the multiplicity of l: the same condition estimate)
         const bool spd = chol_spd<NB>(S, lane);
         if (P.cond_limit > 0.f) {
-            if (row_needs_f64<NB>(S, P, row, spd, lane)) return;
+            if (row_needs_f64<NB>(S, P, row, spd, dual_mean_eig, dual_mean_eig / lam, lane)) return;
         } else if (!spd && lane == 0) atomicMax(P.status, row + 1);
     }
     float w[NS];
