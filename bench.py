@@ -44,6 +44,7 @@ SIZES = {   # name: (m, n, nnz, k)   - cfg4 is the headline; the others are diag
     "cfg4-small": (100_000, 10_000, 5_000_000, 64),       # rehearsal size
     "cfg5-small": (200_000, 20_000, 10_000_000, 128),     # BASELINE configs[4] shape / 50: full model, k = 128
     "cfg5": (10_000_000, 1_000_000, 1_000_000_000, 128),  # BASELINE configs[4] at full size on ONE GPU (~170 GB)
+    "k48": (1_000_000, 100_000, 100_000_000, 48),         # cfg4 shape at KB = 3 (occupancy experiments)
     "k80": (100_000, 10_000, 5_000_000, 80),              # rehearsal size at other ranks (KB = 5, 6, 10)
     "k96": (100_000, 10_000, 5_000_000, 96),
     "k160": (100_000, 10_000, 5_000_000, 160),

@@ -4,7 +4,7 @@
 #   bash profiles/collect_pmc.sh <tag> [bench args]
 set -e
 TAG=${1:-pmc}; shift || true
-ARGS=${@:---steps 2 --warmup 1 --no-cpu-baseline}
+ARGS=${@:---steps 2 --warmup 1 --no-cpu-baseline --no-secondary}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 run() {  # name counters...
   local name=$1; shift

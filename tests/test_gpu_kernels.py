@@ -1,6 +1,8 @@
 """T3 (GPU): each C-ABI entry point against numpy on random CSR, incl. degenerate
 rows (nnz = 1, < k, >> k, > ALS_SPLIT_CHUNK so the split/finish path runs) and
 k in {1, 16, 32, 50, 64, 128}.  Calls go through ctypes -> libals_hip.so."""
+import os
+
 import numpy as np
 import pytest
 
@@ -36,12 +38,29 @@ def _pad(A, ld, extra_rows=0):
     return out
 
 
+def _record_margins(key, worst):
+    """ALS_RECORD_MARGINS=<file>: append the observed errors of a kernel test (the tolerances are set from them)."""
+    path = os.environ.get("ALS_RECORD_MARGINS")
+    if path:
+        import json
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[key] = worst
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+
+
 @pytest.mark.parametrize("gram", ["f16x2", "f32", "f64"])
 @pytest.mark.parametrize("k", [1, 16, 32, 50, 64, 80, 96, 112, 128, 160])
 def test_row_solve_against_numpy(k, gram):
     torch, layout, side_dev, tasks_dev, be, dev = _env(gram)
-    # fp32 solve: rtol 2e-3 / 2e-4 of max|x|; fp64 solve: what is left is the fp32 rounding of the stored x
-    xr, xa, ba, gr, ga = (2e-6, 2e-6, 2e-6, 2e-7, 2e-7) if gram == "f64" else (2e-3, 2e-4, 2e-4, 1e-4, 1e-5)
+    # Tolerances at about 10x the error observed on the MI355X over all k and row lengths of this test
+    # (profiles/r03_kernel_test_margins.json, written by this test under ALS_RECORD_MARGINS=<file>), relative to
+    # max|x| of the row / max|G|: fp32 solve x observed 6.8e-6 (f16x2) / 2.8e-6 (f32), bias 1.5e-7, Gram 7.3e-7
+    # (f16x2) / 3.0e-6 (f32: the f32-MFMA chain is the less accurate one on the 8200-rating row); fp64 mode: the
+    # fp32 rounding of the stored x and Gram, 5.7e-8.  (Round 2 had rtol 2e-3 / atol 2e-4 here: a two-digit
+    # regression would have passed.)
+    xr, xa, ba, gr, ga = (0.0, 6e-7, 6e-7, 0.0, 6e-7) if gram == "f64" else (0.0, 6e-5, 2e-6, 0.0, 2.5e-5)
+    gram_name = gram
+    worst = {"x": 0.0, "bias": 0.0, "gram": 0.0}
     ncols = 9000
     lens = [1, 2, 0, k // 2 + 1, k, 3 * k + 5, 700, 0, 4096, 4097, 8200 + k, 33, 64, 65, 5]
     nrows = len(lens)
@@ -93,16 +112,20 @@ def test_row_solve_against_numpy(k, gram):
         b = Fr.T @ rr + rhs_extra.astype(np.float32)[r].astype(np.float64)
         x = np.linalg.solve(A, b)
         scale = max(np.max(np.abs(x)), 1e-6)
+        worst["x"] = max(worst["x"], float(np.max(np.abs(X[r, :k] - x)) / scale))
         np.testing.assert_allclose(X[r, :k], x, rtol=xr, atol=xa * scale, err_msg=f"row {r} nnz {hi - lo}")
         assert np.all(X[r, k:] == 0.0)
         bref = np.sum(vals - Fr @ x - mu - b_other.astype(np.float32)[idx]) / ((hi - lo) + lam_b + 1e-10)
+        worst["bias"] = max(worst["bias"], abs(bias[r] - bref) / max(1.0, abs(bref)))
         assert abs(bias[r] - bref) <= ba * max(1.0, abs(bref)), (r, bias[r], bref)
         Gr = G[r][np.ix_(pos, pos)]
         blk = pos // 16
         lower_block = blk[:, None] >= blk[None, :]            # documented valid region
         ref = Fr.T @ Fr
+        worst["gram"] = max(worst["gram"], float(np.max(np.abs(Gr - ref)[lower_block]) / max(np.max(np.abs(ref)), 1e-6)))
         np.testing.assert_allclose(Gr[lower_block], ref[lower_block], rtol=gr,
                                    atol=ga * max(np.max(np.abs(ref)), 1e-6))
+    _record_margins(f"row_solve k={k} {gram_name}", worst)
 
 
 @pytest.mark.parametrize("k", [16, 50, 64, 128])
@@ -225,9 +248,9 @@ def test_factor_mode_and_gs_level(k, gram):
         sl = slice(S_ptr[i], S_ptr[i + 1])
         b = Fr.T @ rr + alpha * (S_val[sl].astype(np.float64) @ Vold[S_idx[sl]].astype(np.float64))
         x = np.linalg.solve(A, b)
-        np.testing.assert_allclose(Vn[i, :k], x, rtol=2e-3, atol=2e-4 * max(np.max(np.abs(x)), 1e-6))
+        np.testing.assert_allclose(Vn[i, :k], x, rtol=0, atol=1e-4 * max(np.max(np.abs(x)), 1e-6))      # ~10x observed
         bref = np.sum(vals - Fr @ x - mu - b_other[idx]) / ((hi - lo) + lam_b + 1e-10)
-        assert abs(bn[i] - bref) <= 2e-4 * max(1.0, abs(bref))
+        assert abs(bn[i] - bref) <= 2e-5 * max(1.0, abs(bref))
 
 
 @pytest.mark.parametrize("k", [1, 16, 50, 64, 96, 128, 160])
@@ -408,16 +431,16 @@ def test_dual_form_short_rows_against_numpy_and_the_primal_kernel(k):
         x = np.linalg.solve(A, Fr.T @ (rb - b_self[r]))
         scale = max(np.max(np.abs(x)), 1e-6)
         for X, tag in ((Xd, "dual"), (Xp, "primal")):
-            np.testing.assert_allclose(X[r, :k], x, rtol=2e-3, atol=2e-4 * scale, err_msg=f"{tag} row {r} nnz {hi - lo}")
+            np.testing.assert_allclose(X[r, :k], x, rtol=0, atol=1e-4 * scale, err_msg=f"{tag} row {r} nnz {hi - lo}")
             assert np.all(X[r, k:] == 0.0)
         bref = np.sum(rb - Fr @ x) / ((hi - lo) + lam_b + 1e-10)
         d = rb - Fr @ x - bref
         for b_, s_, tag in ((bd, sd_, "dual"), (bp, sp, "primal")):
-            assert abs(b_[r] - bref) <= 2e-4 * max(1.0, abs(bref)), (tag, r)
+            assert abs(b_[r] - bref) <= 2e-5 * max(1.0, abs(bref)), (tag, r)
             assert abs(s_[r, 0] - d.sum()) <= 2e-4 * max(1.0, np.abs(d).sum()), (tag, r, s_[r, 0], d.sum())
             assert abs(s_[r, 1] - (d * d).sum()) <= 1e-3 * max(1.0, (d * d).sum()), (tag, r, s_[r, 1], (d * d).sum())
     # the two forms are different roundings of the same solution
-    np.testing.assert_allclose(Xd, Xp, rtol=2e-3, atol=2e-4 * np.abs(Xp).max())
+    np.testing.assert_allclose(Xd, Xp, rtol=0, atol=1e-4 * np.abs(Xp).max())
 
 
 def test_dual_classes_are_ignored_by_calls_with_byproducts():
