@@ -313,6 +313,13 @@ def build_similarity_device(X, topk: Optional[int], eps: float, device, block: i
     if (lib is not None and topk is not None and topk < Xshape[0] and topk <= TOPK_KERNEL_MAX_K
             and Xshape[1] <= TOPK_KERNEL_MAX_D and torch.device(device).type == "cuda"):
         return build_similarity_kernel(lib, X, topk, eps, device)
+    if lib is not None and torch.device(device).type == "cuda":
+        # not silently: the caller asked for the kernels and gets the O(n^2) blocked torch formulation instead
+        import logging
+        logging.getLogger(__name__).warning(
+            "graph_build='device': %d feature columns / top-k %s are outside what the top-k kernels take "
+            "(d <= %d, top-k <= %d < n); building the graph with the blocked torch formulation instead",
+            Xshape[1], topk, TOPK_KERNEL_MAX_D, TOPK_KERNEL_MAX_K)
     Xd = torch.as_tensor(np.asarray(X), device=device)
     n = Xd.shape[0]
     Xn = Xd / (torch.sqrt((Xd * Xd).sum(1, keepdim=True)) + eps)
