@@ -72,7 +72,7 @@ extern "C" int als_host_row_tasks(const int64_t* indptr, int64_t row_begin, int6
                                   int32_t dual_len, int32_t mid_len, als_task* tasks, als_long_row* long_rows,
                                   int64_t* counts) {
     if (!indptr || !counts || row_begin < 0 || row_end < row_begin || chunk < 1) return ALS_E_BADARG;
-    int64_t ntasks = 0, nlong = 0, nslots = 0, nnz = 0, ndual = 0, nmid = 0;
+    int64_t ntasks = 0, nlong = 0, nslots = 0, nnz = 0, ndual = 0, nmid = 0, nfull = 0;
     // bucket sizes by segment length (1 .. chunk), three classes: 0 = everything else, 1 = mid, 2 = dual tail
     std::vector<int64_t> bucket(3 * ((size_t)chunk + 1), 0);
     auto cls_of = [&](int64_t len, bool whole) { return whole && len <= dual_len ? 2 : (whole && len <= mid_len ? 1 : 0); };
@@ -86,6 +86,7 @@ extern "C" int als_host_row_tasks(const int64_t* indptr, int64_t row_begin, int6
             nslots += nseg;
             ntasks += nseg;
             bucket[(size_t)chunk] += nseg - 1;
+            nfull += nseg - 1;
             bucket[(size_t)(c - (nseg - 1) * chunk)] += 1;
         } else {
             ++ntasks;
@@ -108,17 +109,30 @@ extern "C" int als_host_row_tasks(const int64_t* indptr, int64_t row_begin, int6
             acc += bucket[(size_t)cls * (chunk + 1) + len];
         }
     int64_t slot = 0, li = 0;
+    // Every segment of a split row but its last has exactly `chunk` ratings.  Those go first, ordered by the
+    // QUANTILE of the row they cover, (seg + 1/2) / nseg, not row by row: a row's ratings are stored in ascending
+    // index of the other side, so workgroups that run at the same time then gather from overlapping slices of
+    // the other side's factor table (cache-resident) instead of the whole table.  V-step at cfg 4: -5.6 % time
+    // (profiles/r03_ab_segment_order.txt).  Slots - the order partial sums are added in - do not change.
+    struct FullSeg { int64_t num, den; als_task t; };           // key = num / den = (2 seg + 1) / (2 nseg)
+    std::vector<FullSeg> full;
+    full.reserve((size_t)nfull);
+    const int64_t full_base = start[(size_t)chunk];              // they lead the length-`chunk` bucket
+    start[(size_t)chunk] += nfull;
     for (int64_t r = row_begin; r < row_end; ++r) {              // segments of split rows
         const int64_t c = indptr[r + 1] - indptr[r];
         const int64_t nseg = c > 0 ? (c + chunk - 1) / chunk : 0;
         if (nseg <= 1) continue;
         long_rows[li++] = als_long_row{(int32_t)r, (int32_t)slot, (int32_t)nseg, 0};
-        for (int64_t s = 0; s < nseg; ++s) {
-            const int64_t len = std::min<int64_t>(chunk, c - s * chunk);
-            tasks[start[(size_t)len]++] = als_task{(int32_t)r, (int32_t)s, (int32_t)(slot + s), 0};
-        }
+        for (int64_t s = 0; s + 1 < nseg; ++s)
+            full.push_back(FullSeg{2 * s + 1, 2 * nseg, als_task{(int32_t)r, (int32_t)s, (int32_t)(slot + s), 0}});
+        const int64_t len = c - (nseg - 1) * chunk;
+        tasks[start[(size_t)len]++] = als_task{(int32_t)r, (int32_t)(nseg - 1), (int32_t)(slot + nseg - 1), 0};
         slot += nseg;
     }
+    std::stable_sort(full.begin(), full.end(),
+                     [](const FullSeg& a, const FullSeg& b) { return a.num * b.den < b.num * a.den; });
+    for (size_t i = 0; i < full.size(); ++i) tasks[full_base + (int64_t)i] = full[i].t;
     for (int64_t r = row_begin; r < row_end; ++r) {              // whole rows
         const int64_t c = indptr[r + 1] - indptr[r];
         if (c <= 0 || c > chunk) continue;

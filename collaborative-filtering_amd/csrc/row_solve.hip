@@ -158,12 +158,19 @@ constexpr int FLUSH_GROUPS = 16;
 
 template <int KB>
 __device__ __forceinline__ void flush_acc(RowAcc<KB>& A, float* __restrict__ Ls, int lane, bool first) {
+    // (`first` is wave-uniform; all the reads of the running totals are issued before the first add so that
+    // the flush costs one LDS round trip, not one per value)
+    if (!first) {
+#pragma unroll
+        for (int a = 0; a < KCfg<KB>::NACC; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A.acc[a][r] += Ls[(a * 4 + r) * 64 + lane];
+    }
 #pragma unroll
     for (int a = 0; a < KCfg<KB>::NACC; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int i = (a * 4 + r) * 64 + lane;
-            Ls[i] = first ? A.acc[a][r] : Ls[i] + A.acc[a][r];
+            Ls[(a * 4 + r) * 64 + lane] = A.acc[a][r];
             A.acc[a][r] = 0.f;
         }
 }

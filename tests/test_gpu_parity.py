@@ -71,7 +71,8 @@ TOL64 = dict(hist=1e-7, norms=2e-6, test_rmse=1e-7, f_rtol=1e-4, f_atol=5e-5, bi
 # 2e-6; float64 mode 2.3e-5 / 7.5e-5 / 4e-7; with the f32-MFMA Gram (the less accurate of the two Gram modes, see
 # profiles/r03_ubench_gram_f16x2.txt) W 3.8e-3, predictions 1.2e-2, fold RMSE 4.5e-5 - inside the 1e-4 budget.
 TOL_ILL_POSED = {"g12_wlam0_k80": dict(test_rmse=1e-5, pred=2e-3, f_atol=4e-4)}
-TOL_ILL_POSED_F32_GRAM = {"g12_wlam0_k80": dict(test_rmse=1e-4, pred=5e-2, f_atol=2e-2, f_rtol=0.0)}
+# (the f32-MFMA Gram also moves the third-iteration ||V|| by 3.4e-6 relative on this fixture: norms 2e-5)
+TOL_ILL_POSED_F32_GRAM = {"g12_wlam0_k80": dict(test_rmse=1e-4, pred=5e-2, f_atol=2e-2, f_rtol=0.0, norms=2e-5)}
 
 
 def _tol_for(name, base, gram=None):

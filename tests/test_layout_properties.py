@@ -31,6 +31,13 @@ def test_row_tasks_cover_every_rating_once(lens, chunk, data):
     for row, slot0, nslots, _ in t.long_rows:                            # consecutive slots per long row
         segs = sorted((int(s), int(sl)) for r, s, sl, _ in t.tasks if r == row)
         assert [sl for _, sl in segs] == list(range(slot0, slot0 + nslots))
+    # the inner (full-length) segments of split rows lead the list, in ascending quantile (seg + 1/2) / nseg of
+    # the row they cover (cache locality of the gathers; slots - the summation order - are untouched)
+    nseg_of = {int(r): int(ns) for r, _, ns, _ in t.long_rows}
+    inner = [(int(r), int(s)) for r, s, sl, _ in t.tasks if sl >= 0 and s < nseg_of[int(r)] - 1]
+    assert [(int(r), int(s)) for r, s, _, _ in t.tasks[:len(inner)]] == inner
+    q = [(2 * s + 1) / (2.0 * nseg_of[r]) for r, s in inner]
+    assert q == sorted(q)
     lens_sorted = [min(chunk, indptr[r + 1] - indptr[r] - s * chunk) for r, s, _, _ in t.tasks]
     assert t.nmid == 0                                                    # mid_len defaults to 0
     head, tail = lens_sorted[:len(lens_sorted) - t.ndual], lens_sorted[len(lens_sorted) - t.ndual:]
