@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Distribution of the per-row condition estimate kappa = (max L_ii / min L_ii)^2 that solve_dtype="auto" decides on
-(als_row_solve_params::cond_limit): the headline workload (cfg4, rows of both half-steps after a few iterations) and
-the small-lambda fixtures.  The limit must sit above the former (cost of auto at cfg4 = 0) and below the latter.
+"""Distribution of the per-row condition estimate that solve_dtype="auto" decides on (als_row_solve_params::cond_limit,
+row_solve.hip::row_needs_f64): kappa = max( (max L_ii / min L_ii)^2,  (trace(G) / rank + lambda) / min L_ii^2,
+mean eigenvalue / lambda for rows of fewer than 4 k ratings ).  The headline workload (cfg4, rows of both half-steps
+after a few iterations, by row length) and the small-lambda / ill-posed fixtures.  The limit (backend.COND_LIMIT = 300)
+must sit above the former (cost of auto at the BASELINE shapes = 0) and below the rows whose fp32 solve leaves the budget.
     python profiles/cond_estimates.py [size] > profiles/r03_cond_estimates.txt"""
 import os
 import sys
