@@ -165,12 +165,14 @@ typedef struct als_row_solve_params {
     const als_task*     tasks;      int64_t ntasks;
     const als_long_row* long_rows;  int64_t nlong;
     void*          workspace;
-    /* Conditioning-driven precision (solve_dtype "auto"): with cond_limit > 0 every row's condition estimate
-     * kappa = (max_i L_ii / min_i L_ii)^2 <= cond_2(A) is taken from the fp32 factorisation; a row with kappa >
-     * cond_limit (or whose fp32 factorisation breaks down) writes none of its results - its row id is appended to
-     * redo_rows (order irrelevant) and the call then redoes exactly those rows in fp64 (Gram, factorisation,
-     * substitutions: the kernel of ALS_GRAM_F64 on the whole row).  The relative error of an fp32 row is then
-     * bounded by about cond_limit * 3e-7 (the fp32 rounding of its Gram).  f32 / f16x2 modes only. */
+    /* Conditioning-driven precision (solve_dtype "auto"): with cond_limit > 0 every row's condition estimate is taken
+     * from what the fp32 factorisation leaves in registers - kappa = max( (max_i L_ii / min_i L_ii)^2,
+     * (trace(G) / rank + lambda) / min_i L_ii^2, and for rows of fewer than 4 k ratings (mean eigenvalue) / lambda ),
+     * three lower bounds of cond_2(A).  A row with kappa > cond_limit (or whose fp32 factorisation breaks down, or
+     * whose closed-form statistics would cancel) writes none of its results - its row id is appended to redo_rows
+     * (order irrelevant) and the call then redoes exactly those rows in fp64 (Gram, factorisation, substitutions:
+     * the kernel of ALS_GRAM_F64 on the whole row).  The relative error of an fp32 row is then bounded by about
+     * cond_limit * 3e-7 (the fp32 rounding of its Gram).  f32 / f16x2 modes only. */
     float          cond_limit;          /* 0 = off */
     int32_t        byproducts_f64;      /* ALS_GRAM_F64 only, != 0: gram_out, rhs_out, colsum_out, sumr_out, sumr2_out are
                                            arrays of DOUBLE (same shapes) - for the W-step / item statistics in fp64
