@@ -288,6 +288,16 @@ __device__ __forceinline__ void st_agent(float* p, float v) {
     __hip_atomic_store(reinterpret_cast<int*>(p), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Profiling builds (-DALS_GS_STAMPS, profiles/sweep_phase_stamps.py): per-phase s_memtime totals of the dataflow sweep,
+// summed over all waves and items: [0] items, [1] requests (descriptor, factor column, rhs) until all have landed,
+// [2] non-dependency gather, [3] dependency batches (polls + waits), [4] substitutions, [5] publication + epilogue.
+#ifdef ALS_GS_STAMPS
+__device__ unsigned long long g_gs_stamps[8];
+#define GS_STAMP(slot) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[slot] += now_ - st_t; st_t = now_; } while (0)
+#else
+#define GS_STAMP(slot) do { } while (0)
+#endif
+
 // k <= 64: factor column in registers, 4 waves per workgroup.  k > 64, two forms:
 //   image  (STREAM = false) one wave per workgroup, the item's factor staged as a [KP][KP+1] LDS image before
 //          the waits - shortest hop (chain-bound sweeps), but 67 KB per wave leave 2 waves per CU;
@@ -311,7 +321,10 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
     using D = DfCfg<KB, STREAM>;
     constexpr int LD = D::LD;
     constexpr bool IMAGE = D::IMAGE;
-    constexpr unsigned long long SPIN_LIMIT = 1ull << 22;      // ~42 ms of the 100 MHz memtime clock
+    // s_memtime ticks at the shader clock (~2.2 GHz measured, profiles/r03_placed_sweep.txt), not at 100 MHz as
+    // rounds 1-2 assumed: 2^22 ticks were 1.9 ms - enough for a resident launch, but a spurious "not resident" as soon
+    // as anything else holds compute units for a moment.  2^27 ticks = ~60 ms.
+    constexpr unsigned long long SPIN_LIMIT = 1ull << 27;
     __shared__ float lds_img[D::IMG];
     float* Al = lds_img;
     float* vec = lds_img + (IMAGE ? KP * LD : 0);
@@ -324,6 +337,10 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
         ic[rr] = min(lane + 64 * rr, KP - 1);
         col[rr] = perm_to_col<KB>(ic[rr]);
     }
+#ifdef ALS_GS_STAMPS
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st_t = __builtin_amdgcn_s_memtime();
+#endif
     for (int64_t it = gw; it < nitems; it += nwaves) {
         const int item = P.items[it];
         const int64_t i64 = item;
@@ -372,6 +389,11 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
         // as soon as all its words are there.  The order of the floating-point sum never depends on timing:
         // the sweep is bitwise reproducible.
         constexpr int GB = (NR == 1) ? 16 : 8;
+#ifdef ALS_GS_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_acc[0] += 1;
+        GS_STAMP(1);
+#endif
         if (nondep) {           // pass 1 was done for all items in parallel by k_gs_nondep (same sums, same order)
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr) g[rr] = nondep[i64 * P.ld + col[rr]];
@@ -396,6 +418,7 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
                     for (int rr = 0; rr < NR; ++rr) g[rr] = fmaf(sv[e], vv[e][rr], g[rr]);
             }
         }
+        GS_STAMP(2);
         // (the next chunk's indices and weights are fetched before this chunk's dependencies are waited for)
         int raw_n = (s0 + lane < s1) ? Sw[s0 + lane] : item;
         float sv_n = (s0 + lane < s1) ? P.S_val[s0 + lane] : 0.f;
@@ -485,6 +508,7 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
                     for (int rr = 0; rr < NR; ++rr) g[rr] += gp[bb][rr];
             }
         }
+        GS_STAMP(3);
         float x[NR], y[NR];
         if constexpr (KB <= 4) {
             x[0] = solve_regs<KP>(a, di0, rhs_i[0] + P.alpha * g[0], lane, &y[0]);
@@ -502,6 +526,10 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
             for (int rr = 0; rr < NR; ++rr) x[rr] = vec[ic[rr]];
             wave_lds_sync();                 // the image is refilled for the next item
         }
+#ifdef ALS_GS_STAMPS
+        if (x[0] == 1.2345e-30f) st_acc[4] += 1;      // (keeps the stamp behind the substitutions)
+        GS_STAMP(4);
+#endif
         // publish first (write-through stores into the publication buffer; each word is its own "ready"
         // flag); V itself is read again only by later launches.  The bias and the statistics below are
         // nobody's dependency.
@@ -537,7 +565,12 @@ void k_gs_dataflow(const als_gs_sweep_params P, const int32_t* __restrict__ Sw, 
                 P.stat_out[2 * i64 + 1] = (float)(s2v - 2.0 * cross + quad);
             }
         }
+        GS_STAMP(5);
     }
+#ifdef ALS_GS_STAMPS
+    if (lane == 0)
+        for (int q = 0; q < 6; ++q) atomicAdd(&g_gs_stamps[q], st_acc[q]);
+#endif
 }
 
 // Pass 1 of the dataflow sweep for ALL listed items at once: g_i = sum over the neighbours j of i that are NOT
@@ -695,6 +728,14 @@ extern "C" int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t
     }
     return ALS_E_BADK;
 }
+
+#ifdef ALS_GS_STAMPS
+extern "C" int als_debug_gs_stamps(unsigned long long* out) {          // profiling builds only: read and reset
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gs_stamps), sizeof(z)) != hipSuccess) return ALS_E_LAUNCH;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_gs_stamps), z, sizeof(z)) == hipSuccess ? 0 : ALS_E_LAUNCH;
+}
+#endif
 
 extern "C" int als_gs_sweep_levels(const als_gs_sweep_params* p, const int64_t* level_offsets,
                                    int64_t nlevels, void* stream) {
