@@ -233,7 +233,7 @@ int als_gs_sweep(const als_gs_sweep_params* p, void* stream);
  * [nrows][ld]: when given, the neighbour sums that do not depend on the sweep (edges without the wait flag) are
  * formed for all items by one parallel launch before the persistent one - same sums, same order, off the
  * dependency chain.  err: int32[1], the caller
- * zeroes it once; set to 1 when a dependency wait exceeded its bound (~40 ms: the launch was not resident as a
+ * zeroes it once; set to 1 when a dependency wait exceeded its bound (2^27 shader-clock ticks, ~60 ms: the launch was not resident as a
  * whole because something else held compute units).  Results are then invalid and the caller should redo the
  * sweep - from the state before it - with als_gs_sweep_levels, which has no residency requirement. */
 int als_gs_sweep_dataflow(const als_gs_sweep_params* p, const int32_t* S_idx_wait, float* publish,
