@@ -675,6 +675,21 @@ class _Engine:
         self.rhs_out = local(self.ld) if need_byproducts else None
         self.colsum_out = local(self.ld) if need_byproducts else None
         self.gram = local(self.ld, self.ld) if self.feat_names else None
+        # Rank-local by-products scale with the rank's ITEM COUNT (factor / gram: ld^2 per item), the shards are cut by
+        # cost (ratings + c rows): when item ids correlate with popularity the tail shard holds more than n / world
+        # items.  Say so instead of letting the "n / world rows" memory statement fail silently.
+        elt = 8 if self.v_f64 else 4
+        self.byproduct_bytes = nloc * elt * ((self.ld * self.ld if self.use_graph else 0)
+                                             + (self.ld * self.ld if self.feat_names else 0)
+                                             + (2 * self.ld if need_byproducts else 0))
+        if self.multi and lib is not None:
+            even = -(-self.n // self.world)
+            logger.info("rank %d: %d of %d items, %.2f GB of V-step by-products", self.rank, nloc, self.n,
+                        self.byproduct_bytes / 1e9)
+            if nloc > 1.5 * even + 64:
+                logger.warning("rank %d holds %d items (even share %d): its V-step by-products take %.2f GB, %.1fx the "
+                               "even share - item ids correlate with popularity; shards are balanced by cost, not by "
+                               "item count", self.rank, nloc, even, self.byproduct_bytes / 1e9, nloc / max(even, 1))
 
         # --- fused statistics (DESIGN.md "Statistics"): without features Z == V, so the residual
         #     sums of an iteration follow in closed form from what the V-step already holds
