@@ -132,7 +132,14 @@ struct KCfg {
     // conflict-free; measured: no change in time, 6.87 / 6.92 vs 6.92 / 6.84 ms.  The LDS pipe is ~30 % busy and
     // a 2-way conflict on ds_write_b32 / ds_read_b32 hides behind the instruction's own issue cycles.)
     // waves per workgroup / minimum waves per SIMD asked of the register allocator
-    static constexpr int WPW = (KB <= 4) ? 4 : (KB <= 6 ? 2 : 1);
+    // ONE wave per workgroup (round 3; rounds 1-2: 4 / 2 / 1 by model width).  The waves of a workgroup never
+    // exchange anything, so a larger workgroup only coarsens the granularity at which the dispatcher refills a CU: all
+    // waves of a workgroup must have finished before its registers and LDS go to the next one.  cfg 4, same box:
+    // U-step 6.17 -> 6.02 ms, V-step 4.51 -> 4.49 ms, bit-identical (profiles/r03_ab_waves_per_workgroup.txt).
+#ifndef ALS_WPW
+#define ALS_WPW 1
+#endif
+    static constexpr int WPW = ALS_WPW;
 #ifndef ALS_MINW_LE4
 #define ALS_MINW_LE4 3      // (tunable of development builds; 4 = 128 registers spills in K1)
 #endif

@@ -132,7 +132,19 @@ extern "C" int als_host_row_tasks(const int64_t* indptr, int64_t row_begin, int6
     }
     std::stable_sort(full.begin(), full.end(),
                      [](const FullSeg& a, const FullSeg& b) { return a.num * b.den < b.num * a.den; });
-    for (size_t i = 0; i < full.size(); ++i) tasks[full_base + (int64_t)i] = full[i].t;
+    // ... and dealt over the XCDs: als_row_solve runs task b in workgroup b (one wave per workgroup), which the
+    // dispatcher places on XCD b % ALS_NXCD, so position b receives element (b % 8) * (n / 8) + b / 8 of the quantile
+    // order (bijective form for n % 8 != 0): every XCD works its way through ONE contiguous eighth of the order - its
+    // own slice of the factor table in its own L2 - instead of all eight sharing every slice.  V-step at cfg 4:
+    // another -5 % (profiles/r03_ab_xcd_interleave.txt).  Placement is a speed matter only.
+    {
+        const int64_t nf = (int64_t)full.size(), q = nf / ALS_NXCD, r = nf % ALS_NXCD;
+        for (int64_t b = 0; b < nf; ++b) {
+            const int64_t x = b % ALS_NXCD;
+            const int64_t src = nf < 2 * ALS_NXCD ? b : (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / ALS_NXCD;
+            tasks[full_base + b] = full[(size_t)src].t;
+        }
+    }
     for (int64_t r = row_begin; r < row_end; ++r) {              // whole rows
         const int64_t c = indptr[r + 1] - indptr[r];
         if (c <= 0 || c > chunk) continue;

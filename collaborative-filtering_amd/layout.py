@@ -23,6 +23,7 @@ import numpy as np
 DUAL_MAX_LEN = 64        # rows this short may be solved in the dual form (csrc/row_solve.hip, k_row_dual)
 DUAL_MID_LEN = 96        # ... and, above k = 96, rows up to this length (k_row_dual_mid)
 SPLIT_CHUNK = 4096          # == ALS_SPLIT_CHUNK in include/als_hip.h
+NXCD = 8                    # == ALS_NXCD: XCDs (private L2s) of the MI355X
 
 
 def padded_k(k: int) -> int:
@@ -155,6 +156,16 @@ def build_row_tasks(indptr: np.ndarray, row_begin: int = 0, row_end: Optional[in
     grp = np.concatenate([np.where(inner, 0, 1), np.full(s_rows.size, 2)])
     key = np.concatenate([np.where(inner, (2 * t_seg + 1) / (2.0 * np.maximum(rep_nseg, 1)), 0.0), np.zeros(s_rows.size)])
     order = np.lexsort((np.arange(all_len.size), key, grp, -all_len))
+    # ... and dealt over the XCDs: als_row_solve runs task b in workgroup b (one wave per workgroup), which the
+    # dispatcher places on XCD b % NXCD, so position b receives element (b % 8) * (n / 8) + b / 8 of the quantile order
+    # (bijective form for n % 8 != 0): every XCD works through ONE contiguous eighth of the order - its own slice of the
+    # factor table in its own L2 - instead of all eight sharing every slice.
+    nf = int(inner.sum())
+    if nf >= 2 * NXCD:
+        b = np.arange(nf)
+        q, r = divmod(nf, NXCD)
+        x = b % NXCD
+        order[:nf] = order[:nf][np.where(x < r, x * (q + 1), r * (q + 1) + (x - r) * q) + b // NXCD]
     # whole rows of at most `dual_len` ratings go last (longest-first inside both parts): als_row_solve may
     # hand that tail to the dual-form kernel (`ndual_tail`, k > 64)
     # ... preceded by the whole rows of dual_len < n <= mid_len ratings (`ndual_mid`, k > 96)

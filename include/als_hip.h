@@ -35,6 +35,7 @@ extern "C" {
 #endif
 
 #define ALS_HIP_VERSION 102
+#define ALS_NXCD 8             /* XCDs (private L2s) of the MI355X: als_host_row_tasks deals equal-length tasks over them */
 
 #define ALS_E_BADARG   (-1)
 #define ALS_E_BADK     (-2)   /* k outside 1..ALS_MAX_K */
