@@ -63,8 +63,9 @@ __device__ __forceinline__ void process_chunk(RowAcc<KB>& A, int off_l, float r_
         // all cross-lane moves of the group first (one LDS-crossbar round trip), then the loads
 #pragma unroll
         for (int s = 0; s < GS; ++s) {
-            off_t[s] = bperm_i(off_l, 4 * (g0 + s) + q);
-            r_t[s] = bperm_f(r_l, 4 * (g0 + s) + q);
+            const int src = FULL ? 16 * q + g0 + s : 4 * (g0 + s) + q;     // full chunks: rows 16 ratings apart (see below)
+            off_t[s] = bperm_i(off_l, src);
+            r_t[s] = bperm_f(r_l, src);
         }
 #pragma unroll
         for (int s = 0; s < GS; ++s)
@@ -114,8 +115,13 @@ __device__ __forceinline__ void process_chunk_f16x2(RowAcc<KB>& A, int off_l, fl
         float f[8][KB];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            off_t[j] = bperm_i(off_l, 32 * g + 8 * q + j);
-            r_t[j] = bperm_f(r_l, 32 * g + 8 * q + j);
+            // which rating goes to which k-element is free (A and B operands use the same assignment).  Full
+            // chunks: lane group q takes ratings 16 q + 8 g + j, so the four rows ONE gather instruction fetches are
+            // 16 ratings apart (8 apart with 32 g + 8 q + j: cfg 4 V-step +2.7 %, U-step +1.5 %; 1 apart: V-step
+            // +7 % - profiles/r03_ab_gather_row_spread.txt).  A partial chunk keeps its valid ratings in group 0.
+            const int src = FULL ? 16 * q + 8 * g + j : 32 * g + 8 * q + j;
+            off_t[j] = bperm_i(off_l, src);
+            r_t[j] = bperm_f(r_l, src);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) load_frow<KB>(Fc + (uint32_t)off_t[j], f[j]);
