@@ -40,7 +40,7 @@ class RowSolveParams(C.Structure):
         ("status", _vp),
         ("tasks", _vp), ("ntasks", _i64), ("long_rows", _vp), ("nlong", _i64),
         ("workspace", _vp), ("cond_limit", _f32), ("byproducts_f64", _i32), ("redo_count", _vp), ("redo_rows", _vp),
-        ("cond_out", _vp), ("F_scale", _vp),
+        ("cond_out", _vp), ("F_scale", _vp), ("F_planes", _vp),
     ]
 
 

