@@ -110,11 +110,13 @@ class HipBackend:
         # pre-split operands (als_row_solve_params::F_planes): k = 49 ... 64, f16x2 Gram, a gathered table small enough
         # that the extra pass over it is noise - in practice the U-step (its table is V / Z); the V-step's table (U) is
         # large and that launch is bound by the gather, not by vector issue
-        if (ld == 64 and not f64 and p.gram_mode == self.GRAM_MODES["f16x2"] and self.planes_max_floats > 0
-                and F.numel() <= self.planes_max_floats and int(zero_row) == F.shape[0] - 1 and F.is_contiguous()):
-            buf = self._planes.get(F.numel())
+        # (the zero row is the table's last row - right behind the view the engine passes as F)
+        nwords = (int(zero_row) + 1) * ld
+        if (ld == 64 and not f64 and p.gram_mode == self.GRAM_MODES["f16x2"] and 0 < nwords <= self.planes_max_floats
+                and int(zero_row) >= F.shape[0] - 1 and F.is_contiguous()):
+            buf = self._planes.get(nwords)
             if buf is None:
-                buf = self._planes[F.numel()] = torch.empty(F.numel(), dtype=torch.int32, device=self.device)
+                buf = self._planes[nwords] = torch.empty(nwords, dtype=torch.int32, device=self.device)
             p.F_planes = _p(buf)
         if self.cond_limit > 0.0 and not self.ablate and not f64:
             if side.nrows not in self._redo_rows:

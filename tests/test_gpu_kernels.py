@@ -128,6 +128,52 @@ def test_row_solve_against_numpy(k, gram):
     _record_margins(f"row_solve k={k} {gram_name}", worst)
 
 
+@pytest.mark.parametrize("k", [50, 64])
+def test_row_solve_presplit_operands_equal_the_in_kernel_split(k):
+    """als_row_solve_params::F_planes (k = 49 ... 64): the Gram from pre-split fp16 operands is the in-kernel split's
+    Gram BIT FOR BIT (same terms, same products, same order); the right-hand side and the column sums come from the
+    matrix cores instead of the vector unit, so x and the bias agree to rounding (every row class: 1 rating, < k, k,
+    long, split rows with partial slots, empty rows untouched)."""
+    torch, layout, side_dev, tasks_dev, _, dev = _env()
+    from collaborative_filtering_amd.backend import HipBackend
+    ncols = 9000
+    lens = [1, 2, 0, k // 2 + 1, k, 3 * k + 5, 700, 0, 4096, 4097, 8200 + k, 33, 64, 65, 5, 511, 513]
+    nrows = len(lens)
+    side = _random_side(layout, nrows, ncols, lens, seed=7 * k)
+    rng = np.random.default_rng(9 + k)
+    ld = layout.padded_k(k)
+    F = rng.normal(scale=0.3, size=(ncols, k)) * 10.0 ** rng.uniform(-2, 0, size=(ncols, 1))      # two decades of row norms
+    b_self, b_other = rng.normal(scale=0.2, size=nrows), rng.normal(scale=0.2, size=ncols)
+    t = layout.build_row_tasks(side.indptr)
+    sd, td = side_dev(side, dev), tasks_dev(t, dev)
+    f32 = torch.float32
+    out = {}
+    for label, planes in (("split", 0), ("planes", HipBackend.PLANES_MAX_FLOATS)):
+        be = HipBackend(dev, solve_dtype="float32")
+        be.planes_max_floats = planes
+        X_out = torch.full((nrows, ld), 7.0, dtype=f32, device=dev)
+        bias_out = torch.full((nrows,), 7.0, dtype=f32, device=dev)
+        gram = torch.zeros(nrows, ld, ld, dtype=f32, device=dev)
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = torch.empty(t.nslots * be.slot_bytes(k) // 4, dtype=f32, device=dev)
+        tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)       # noqa: E731
+        be.row_solve(k=k, ld=ld, side=sd, F=tt(_pad(F, ld, 1)), zero_row=ncols, bias_self=tt(b_self), bias_other=tt(b_other),
+                     mu=torch.tensor([3.3], dtype=torch.float64, device=dev), lam=2.5, lam_row=None, lam_b=1.7,
+                     lam_b_row=None, rhs_extra=None, diag_extra=None, X_out=X_out, bias_out=bias_out, gram_out=gram,
+                     factor_out=None, rhs_out=None, colsum_out=None, sumr_out=None, status=status, tasks=td, workspace=ws)
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0
+        assert (len(be._planes) > 0) == (planes > 0)
+        out[label] = (X_out.cpu().numpy(), bias_out.cpu().numpy(), gram.cpu().numpy())
+    np.testing.assert_array_equal(out["split"][2], out["planes"][2])                     # the Gram: bit for bit
+    xs, xp = out["split"][0].astype(np.float64), out["planes"][0].astype(np.float64)
+    scale = np.maximum(np.max(np.abs(xs), axis=1, keepdims=True), 1e-6)
+    assert np.max(np.abs(xs - xp) / scale) <= 2e-5
+    np.testing.assert_allclose(out["split"][1], out["planes"][1], rtol=0, atol=2e-6)
+    empty = np.diff(side.indptr) == 0
+    assert np.all(out["planes"][0][empty] == 7.0) and np.all(out["planes"][1][empty] == 7.0)
+
+
 @pytest.mark.parametrize("k", [16, 50, 64, 128])
 def test_row_solve_f64_small_lambda(k):
     """ALS_GRAM_F64 at lambda = 1e-4 with rows shorter than k (cond ~ 1/lambda, where the fp32 kernels lose the
