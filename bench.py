@@ -469,6 +469,11 @@ def main(argv=None, *, backend=None, device=None):
             issued, peak_tf, what = sym * 2 * (16 * kb) ** 2 * (nn_u + nn_i), 78.6, "fp64 MFMA flops issued / dense fp64 matrix peak"
         elif args.gram == "f16x2":
             issued, peak_tf, what = 3 * sym * 2 * (16 * kb) ** 2 * (nn_u + nn_i), 2500.0, "fp16 MFMA flops issued (3 per Gram product) / dense fp16 peak"
+            if getattr(eng.be, "_planes", None):
+                # U-step from pre-split operands (als_row_solve_params::F_planes): F^T r / F^T 1 on the matrix cores
+                # too, two more 16x16x32 instructions per column block and 32 ratings
+                issued += 2 * 2 * 16 * (16 * kb) * nn_u
+                what += "; U-step incl. the right-hand-side operand (pre-split operands)"
         else:
             issued, peak_tf, what = sym * 2 * (16 * kb) ** 2 * (nn_u + nn_i), 157.3, "fp32 MFMA flops issued / dense fp32 matrix peak"
         roof["mfma_view"] = {"issued_TFLOPs": issued / t_rs / 1e12, "peak_TFLOPs": peak_tf,
@@ -487,6 +492,7 @@ def main(argv=None, *, backend=None, device=None):
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": ("f32 storage; f64 Gram / Cholesky / substitutions (solve_dtype=float64)" if args.solve_dtype == "float64"
                       else "f32 (storage, solve, accumulate); Gram products as 2-way fp16 split (error <= 2^-23) on fp16 MFMA"
+                           + ("; rows over the condition limit redone in f64 (solve_dtype=auto)" if args.solve_dtype == "auto" else "")
                       if args.gram == "f16x2" else "f32"), "data": "synthetic",
             "config": {"workload": f"{args.size}: {m} users x {n} items, {nnz} ratings, k={k}, bias + "
                                    f"graph-Laplacian (alpha=0.5, {0 if S is None else int(S[1].numel())} graph nnz)"
