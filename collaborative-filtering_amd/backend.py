@@ -27,6 +27,7 @@ class HipBackend:
     GRAM_MODES = {"f32": 0, "f16x2": 1, "f64": 2}
     COND_LIMIT = 300.0
     PLANES_MAX_FLOATS = 16 << 20       # 64 MiB table: V / Z of every BASELINE shape, never U
+    PLANES_MAX_FLOATS_K128 = (1 << 31) - 1     # k = 128: any table als_row_solve accepts (element offsets < 2^31)
 
     def __init__(self, device: torch.device, gram: str = "f16x2", solve_dtype: str = "auto"):
         if gram not in ("f32", "f16x2"):
@@ -54,6 +55,7 @@ class HipBackend:
         # (floats) it is used for; ALS_PLANES=0 switches the path off
         self._planes: dict = {}
         self.planes_max_floats = 0 if os.environ.get("ALS_PLANES", "1") == "0" else self.PLANES_MAX_FLOATS
+        self.planes_max_floats_k128 = self.PLANES_MAX_FLOATS_K128 if os.environ.get("ALS_PLANES_K128") == "1" else 0
         # solve_dtype="auto": rows whose condition estimate (two lower bounds of cond_2 from their own fp32
         # factorisation: the pivot ratio (max L_ii / min L_ii)^2 and (trace(G) / rank + lambda) / min L_ii^2) exceeds
         # COND_LIMIT are redone in fp64 by the same call, as are rows whose closed-form residual statistics cancel to
@@ -111,8 +113,12 @@ class HipBackend:
         # that the extra pass over it is noise - in practice the U-step (its table is V / Z); the V-step's table (U) is
         # large and that launch is bound by the gather, not by vector issue
         # (the zero row is the table's last row - right behind the view the engine passes as F)
+        # k = 113 ... 128: the kernel has the path too (tested), but it measures +-0 there - 124 instead of 108 matrix
+        # instructions per 32 ratings cost what the vector instructions save (cfg 5 / 50: V-step 1.93 -> 1.89 ms,
+        # U-step unchanged) - so it is off unless ALS_PLANES_K128=1
         nwords = (int(zero_row) + 1) * ld
-        if (ld == 64 and not f64 and p.gram_mode == self.GRAM_MODES["f16x2"] and 0 < nwords <= self.planes_max_floats
+        limit = self.planes_max_floats if ld == 64 else (self.planes_max_floats_k128 if ld == 128 else 0)
+        if (not f64 and p.gram_mode == self.GRAM_MODES["f16x2"] and 0 < nwords <= limit
                 and int(zero_row) >= F.shape[0] - 1 and F.is_contiguous()):
             buf = self._planes.get(nwords)
             if buf is None:

@@ -168,10 +168,11 @@ __device__ __forceinline__ void process_chunk_f16x2(RowAcc<KB>& A, int off_l, fl
 // table is small and the launch is bound by vector issue - the U-step: ~60 instead of ~293 vector instructions
 // and 38 instead of 30 matrix instructions per 32 ratings.
 // ---------------------------------------------------------------------------
-template <bool FULL>
-__device__ __forceinline__ void process_chunk_planes(RowAcc<4>& A, f32x4 (&E)[4], int off_l, int rp_l, int nvalid,
+template <int KB, bool FULL>
+__device__ __forceinline__ void process_chunk_planes(RowAcc<KB>& A, f32x4 (&E)[KB], int off_l, int rp_l, int nvalid,
                                                      const uint32_t* __restrict__ Pc, int q, int sel_c, int ones_c) {
-    constexpr int KB = 4;
+    static_assert(KB == 4 || KB == 8, "pre-split operands: k = 49 ... 64 and 113 ... 128");
+    constexpr int NW = KB / 2;              // words of h (and of l) per rating and lane: KB halves each
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -183,9 +184,14 @@ __device__ __forceinline__ void process_chunk_planes(RowAcc<4>& A, f32x4 (&E)[4]
             off_t[j] = bperm_i(off_l, src);
             rp_t[j] = bperm_i(rp_l, src);
         }
-        u32x4 w[8];
+        uint32_t w[8][KB];                   // per rating: (h pairs)[NW] then (l pairs)[NW]
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const u32x4*>(Pc + (uint32_t)off_t[j]);
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int v4 = 0; v4 < KB / 4; ++v4) {
+                const u32x4 t = *reinterpret_cast<const u32x4*>(Pc + (uint32_t)off_t[j] + 4 * v4);
+                w[j][4 * v4] = t[0]; w[j][4 * v4 + 1] = t[1]; w[j][4 * v4 + 2] = t[2]; w[j][4 * v4 + 3] = t[3];
+            }
         i32x4 H[KB], L[KB], R;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -194,7 +200,7 @@ __device__ __forceinline__ void process_chunk_planes(RowAcc<4>& A, f32x4 (&E)[4]
             for (int b = 0; b < KB; ++b) {
                 const uint32_t sel = (b & 1) ? 0x07060302u : 0x05040100u;
                 H[b][d] = (int)__builtin_amdgcn_perm(w[2 * d + 1][b >> 1], w[2 * d][b >> 1], sel);
-                L[b][d] = (int)__builtin_amdgcn_perm(w[2 * d + 1][2 + (b >> 1)], w[2 * d][2 + (b >> 1)], sel);
+                L[b][d] = (int)__builtin_amdgcn_perm(w[2 * d + 1][NW + (b >> 1)], w[2 * d][NW + (b >> 1)], sel);
             }
         }
         const h16x8 rr = __builtin_bit_cast(h16x8, R);
@@ -217,9 +223,10 @@ __device__ __forceinline__ void process_chunk_planes(RowAcc<4>& A, f32x4 (&E)[4]
 }
 
 // E (rows 0, 1, 2 of the lanes q = 0) -> the lane's partial right-hand side / column sums, unscaled; E restarts at zero
-__device__ __forceinline__ void fold_planes_rhs(RowAcc<4>& A, f32x4 (&E)[4], int q, float inv_s) {
+template <int KB>
+__device__ __forceinline__ void fold_planes_rhs(RowAcc<KB>& A, f32x4 (&E)[KB], int q, float inv_s) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < KB; ++b) {
         A.rhs[b] += (q == 0) ? (E[b][0] + E[b][2]) * inv_s : 0.f;
         A.cs[b] += (q == 0) ? E[b][1] * inv_s : 0.f;
         E[b] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -271,14 +278,14 @@ __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __
     const float* Fc = F + KB * c;
     int nflush = 0;
     // MODE 2 (pre-split operands, KB == 4): extra accumulators for R (H + L), the operand-R selectors of this lane
-    f32x4 E[MODE == 2 ? 4 : 1];
+    f32x4 E[MODE == 2 ? KB : 1];
     const uint32_t* Pc = planes + KB * c;
     const int sel_c = (c == 0) ? 0x05040100 : (c == 2) ? 0x07060302 : 0x0c0c0c0c;
     const int ones_c = (c == 1) ? 0x3C003C00 : 0;
     const float inv_s = __int_as_float((254 - ((__float_as_int(S) >> 23) & 0xff)) << 23);      // S is a power of two
     if constexpr (MODE == 2) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) E[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < KB; ++b) E[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // software pipeline over 64-rating chunks: indices two chunks ahead,
     // value + opposite-side bias one chunk ahead of the factor-row gathers
@@ -313,22 +320,22 @@ __device__ __forceinline__ void gram_accumulate(RowAcc<KB>& A, const int32_t* __
                 const _Float16 rh = (_Float16)r0;
                 const _Float16 rl = (_Float16)(r0 - (float)rh);
                 const int rp = (int)__builtin_bit_cast(unsigned short, rh) | ((int)__builtin_bit_cast(unsigned short, rl) << 16);
-                if (nvalid == 64) process_chunk_planes<true>(A, E, off0, rp, 64, Pc, q, sel_c, ones_c);
-                else              process_chunk_planes<false>(A, E, off0, rp, nvalid, Pc, q, sel_c, ones_c);
+                if (nvalid == 64) process_chunk_planes<KB, true>(A, E, off0, rp, 64, Pc, q, sel_c, ones_c);
+                else              process_chunk_planes<KB, false>(A, E, off0, rp, nvalid, Pc, q, sel_c, ones_c);
             } else {
                 if (nvalid == 64) process_chunk_f16x2<KB, true>(A, off0, r0, 64, Fc, q, S);
                 else              process_chunk_f16x2<KB, false>(A, off0, r0, nvalid, Fc, q, S);
             }
             if (((base >> 6) + 1) % (FLUSH_GROUPS / 2) == 0 && base + 64 < len) {
                 mfma_results_settle();
-                if constexpr (MODE == 2) fold_planes_rhs(A, E, q, inv_s);
+                if constexpr (MODE == 2) fold_planes_rhs<KB>(A, E, q, inv_s);
                 flush_acc<KB>(A, Ls, lane, nflush == 0);
                 ++nflush;
             }
         }
     }
     if (MODE != 0) mfma_results_settle();         // whoever reads the accumulators next (totals, partial slot, finish_row)
-    if constexpr (MODE == 2) fold_planes_rhs(A, E, q, inv_s);
+    if constexpr (MODE == 2) fold_planes_rhs<KB>(A, E, q, inv_s);
     if (MODE != 0 && nflush > 0) {
         unflush_acc<KB>(A, Ls, lane);
         wave_lds_sync();
@@ -1046,20 +1053,32 @@ int launch_factor_scale(const float* F, int64_t nfloats, float* scale, int32_t* 
 
 __global__ void k_reset_word(int32_t* w) { *w = 0; }
 
-// F [nrows][64] fp32 -> planes [nrows][64] words: per row and 16-lane column group c the 16-byte piece
-// (h0 h1)(h2 h3)(l0 l1)(l2 l3) of the columns 4 c ... 4 c + 3, h = fp16(x S), l = fp16(x S - h) (split2: the very
-// terms the in-kernel split of ALS_GRAM_F16X2 produces).  One thread per piece.
+// F [nrows][ld] fp32 -> planes [nrows][ld] words (ld = 16 KB, KB = 4 or 8): per row and 16-lane column group c the
+// piece (h pairs)[KB / 2] (l pairs)[KB / 2] of the columns KB c ... KB c + KB - 1, h = fp16(x S), l = fp16(x S - h)
+// (split2: the very terms the in-kernel split of ALS_GRAM_F16X2 produces).  One thread per piece.
+template <int KB>
 __global__ __launch_bounds__(256)
 void k_split_planes(const float* __restrict__ F, int64_t npieces, const float* __restrict__ scale,
                     uint32_t* __restrict__ planes) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const float S = scale[0];
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < npieces; e += (int64_t)gridDim.x * 256) {
-        const f32x4 x = reinterpret_cast<const f32x4*>(F)[e];
-        int h01, l01, h23, l23;
-        split2(x[0], x[1], S, h01, l01);
-        split2(x[2], x[3], S, h23, l23);
-        reinterpret_cast<u32x4*>(planes)[e] = u32x4{(uint32_t)h01, (uint32_t)h23, (uint32_t)l01, (uint32_t)l23};
+        uint32_t h[KB / 2], l[KB / 2];
+#pragma unroll
+        for (int v4 = 0; v4 < KB / 4; ++v4) {
+            const f32x4 x = reinterpret_cast<const f32x4*>(F)[e * (KB / 4) + v4];
+            int h01, l01, h23, l23;
+            split2(x[0], x[1], S, h01, l01);
+            split2(x[2], x[3], S, h23, l23);
+            h[2 * v4] = (uint32_t)h01; h[2 * v4 + 1] = (uint32_t)h23;
+            l[2 * v4] = (uint32_t)l01; l[2 * v4 + 1] = (uint32_t)l23;
+        }
+        if constexpr (KB == 4) {
+            reinterpret_cast<u32x4*>(planes)[e] = u32x4{h[0], h[1], l[0], l[1]};
+        } else {
+            reinterpret_cast<u32x4*>(planes)[2 * e] = u32x4{h[0], h[1], h[2], h[3]};
+            reinterpret_cast<u32x4*>(planes)[2 * e + 1] = u32x4{l[0], l[1], l[2], l[3]};
+        }
     }
 }
 
@@ -1084,12 +1103,13 @@ int launch_row_solve(const als_row_solve_params* p, hipStream_t st) {
         q.ntasks = nprimal;
         const unsigned grid = (unsigned)((nprimal + C::WPW - 1) / C::WPW);
         bool planes = false;
-        if constexpr (KB == 4) planes = p->gram_mode == ALS_GRAM_F16X2 && p->F_planes != nullptr && p->reserved0 == 0;
+        if constexpr (KB == 4 || KB == 8)
+            planes = p->gram_mode == ALS_GRAM_F16X2 && p->F_planes != nullptr && p->reserved0 == 0;
         if (planes) {
-            if constexpr (KB == 4) {
+            if constexpr (KB == 4 || KB == 8) {
                 const int64_t npieces = ((int64_t)p->F_zero_row + 1) * 16;
-                const unsigned sgrid = (unsigned)min((int64_t)2048, (npieces + 255) / 256);
-                hipLaunchKernelGGL(k_split_planes, dim3(sgrid), dim3(256), 0, st, p->F, npieces, p->F_scale,
+                const unsigned sgrid = (unsigned)min((int64_t)4096, (npieces + 255) / 256);
+                hipLaunchKernelGGL(k_split_planes<KB>, dim3(sgrid), dim3(256), 0, st, p->F, npieces, p->F_scale,
                                    (uint32_t*)p->F_planes);
                 hipLaunchKernelGGL((k_row_tasks<KB, 2>), dim3(grid), dim3(64 * C::WPW), 0, st, q);
             }

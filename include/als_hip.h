@@ -185,7 +185,7 @@ typedef struct als_row_solve_params {
     float*         F_scale;             /* ALS_GRAM_F16X2: ALS_FSCALE_FLOATS floats of device memory, zero before the FIRST
                                            use (later calls leave words 2, 3 zero); the call writes {S, 1 / S^2} of F to
                                            words 0, 1 unless F_scale_ready; must not be shared by concurrent calls */
-    void*          F_planes;            /* nullable; ALS_GRAM_F16X2 at k = 49 ... 64: scratch of (F_zero_row + 1) * ld 32-bit
+    void*          F_planes;            /* nullable; ALS_GRAM_F16X2 at k = 49 ... 64 or 113 ... 128: scratch of (F_zero_row + 1) * ld 32-bit
                                            words (F_zero_row must be the LAST row of F).  When given, the call first
                                            writes the two fp16 terms of every element of F into it (same layout as F)
                                            and the Gram is built from those pre-split operands, right-hand side and

@@ -128,9 +128,9 @@ def test_row_solve_against_numpy(k, gram):
     _record_margins(f"row_solve k={k} {gram_name}", worst)
 
 
-@pytest.mark.parametrize("k", [50, 64])
+@pytest.mark.parametrize("k", [50, 64, 120, 128])
 def test_row_solve_presplit_operands_equal_the_in_kernel_split(k):
-    """als_row_solve_params::F_planes (k = 49 ... 64): the Gram from pre-split fp16 operands is the in-kernel split's
+    """als_row_solve_params::F_planes (k = 49 ... 64 and 113 ... 128): the Gram from pre-split fp16 operands is the in-kernel split's
     Gram BIT FOR BIT (same terms, same products, same order); the right-hand side and the column sums come from the
     matrix cores instead of the vector unit, so x and the bias agree to rounding (every row class: 1 rating, < k, k,
     long, split rows with partial slots, empty rows untouched)."""
@@ -150,7 +150,7 @@ def test_row_solve_presplit_operands_equal_the_in_kernel_split(k):
     out = {}
     for label, planes in (("split", 0), ("planes", HipBackend.PLANES_MAX_FLOATS)):
         be = HipBackend(dev, solve_dtype="float32")
-        be.planes_max_floats = planes
+        be.planes_max_floats = be.planes_max_floats_k128 = planes          # (k = 128: off by default, exercised here)
         X_out = torch.full((nrows, ld), 7.0, dtype=f32, device=dev)
         bias_out = torch.full((nrows,), 7.0, dtype=f32, device=dev)
         gram = torch.zeros(nrows, ld, ld, dtype=f32, device=dev)
