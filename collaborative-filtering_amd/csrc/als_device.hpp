@@ -185,7 +185,7 @@ __device__ __forceinline__ float solve_regs(const float (&a)[KP], float di, floa
 // block is requested before the current one is consumed, so registers stay at 2*16*NR for any k.
 // rb enters as b, leaves as x; y_out (optional) receives the forward-solved vector.
 template <int KB>
-__device__ __forceinline__ void solve_stream(const float* __restrict__ M, float (&rb)[KCfg<KB>::NR], int lane,
+__device__ __forceinline__ void solve_stream_plain(const float* __restrict__ M, float (&rb)[KCfg<KB>::NR], int lane,
                                              float* y_out = nullptr) {
     constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR;
     int ic[NR];
@@ -265,6 +265,104 @@ __device__ __forceinline__ void solve_stream(const float* __restrict__ M, float 
     for (int rr = 0; rr < NR; ++rr) rb[rr] = rs[rr];
 }
 
+// k <= 128 (round 3): every step index is a compile-time constant in the unrolled code, so a 64-lane group that a
+// step cannot touch costs nothing, a group that it touches as a whole needs no mask, and the pivot's own group takes a
+// LITERAL lane mask (the compares used to be hoisted out of the item loop and their SGPR pairs spilled into VGPR lanes:
+// two extra v_readlane per step); the next block's loads are pinned in front of the current block's chain.
+template <int KB>
+__device__ __forceinline__ void solve_stream(const float* __restrict__ M, float (&rb)[KCfg<KB>::NR], int lane,
+                                             float* y_out = nullptr) {
+    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR;
+    if constexpr (NR > 2) {
+        solve_stream_plain<KB>(M, rb, lane, y_out);          // (three groups: see lds_fwd_group_plain)
+        return;
+    } else {
+    int ic[NR];
+    float di[NR], rs[NR];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        ic[rr] = min(lane + 64 * rr, KP - 1);
+        di[rr] = M[ic[rr] * KP + ic[rr]];
+        rs[rr] = rb[rr] * di[rr];
+    }
+    float cur[NR][16], nxt[NR][16];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) cur[rr][t] = M[t * KP + ic[rr]];
+    // L y = b, blocks ascending
+#pragma unroll
+    for (int pb = 0; pb < KB; ++pb) {
+        const int nb = (pb + 1 < KB) ? pb + 1 : KB - 1;     // (last: first block of the transposed sweep)
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) nxt[rr][t] = M[(16 * nb + t) * KP + ic[rr]];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int j = 16 * pb + t, jb = j >> 6, t6 = j & 63;
+            const float yj = readlane_f(rs[jb], t6);
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                if (rr < jb) continue;                       // that group's unknowns are final
+                float cf = cur[rr][t] * di[rr];
+                if (rr == jb) {
+                    const unsigned long long mask = (t6 >= 63) ? 0ull : (~0ull << (t6 + 1));     // lanes > t6
+                    cf = __builtin_amdgcn_inverse_ballot_w64(mask) ? cf : 0.f;
+                }
+                rs[rr] = fmaf(-cf, yj, rs[rr]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) cur[rr][t] = nxt[rr][t];
+    }
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        if (y_out) y_out[rr] = rs[rr];      // lane holds y_i
+        rs[rr] *= di[rr];
+    }
+    // L^T x = y, blocks descending (cur already holds the last block)
+#pragma unroll
+    for (int pb = KB - 1; pb >= 0; --pb) {
+        if (pb > 0) {
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) nxt[rr][t] = M[(16 * (pb - 1) + t) * KP + ic[rr]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 15; t >= 0; --t) {
+            const int j = 16 * pb + t, jb = j >> 6, t6 = j & 63;
+            const float xj = readlane_f(rs[jb], t6);
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                if (rr > jb) continue;                       // rows below the pivot's group are not touched
+                float cf = cur[rr][t] * di[rr];
+                if (rr == jb) {
+                    const unsigned long long mask = (t6 <= 0) ? 0ull : ((1ull << t6) - 1ull);     // lanes < t6
+                    cf = __builtin_amdgcn_inverse_ballot_w64(mask) ? cf : 0.f;
+                }
+                rs[rr] = fmaf(-cf, xj, rs[rr]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (pb > 0) {
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) cur[rr][t] = nxt[rr][t];
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) rb[rr] = rs[rr];
+    }
+}
+
 // any KP, L in LDS: Al[j*LD + i] = L[i][j] (i > j), dinv[j] = 1/L[j][j].
 // vec[] (LDS, perm space) holds b on entry and x on exit.
 //
@@ -274,8 +372,11 @@ __device__ __forceinline__ void solve_stream(const float* __restrict__ M, float 
 // at the end, which removes the per-step "lane == j" select.  JB / IB (the 64-lane group of the pivot)
 // is a template parameter, so groups that a step cannot touch cost no instruction and only the pivot's
 // own group needs the i > j (j < ii) mask.
+// k > 128 (three 64-lane groups): the loop form of rounds 1-2.  The unrolled form below is WRONG there inside the
+// persistent dataflow kernel (k = 130 ... 160: fits differ in the 4th digit; the same functions are right in the per-level
+// kernel and at k <= 128 - 395 VGPRs + 139 AGPRs in that kernel, not tracked down), so those widths keep this one.
 template <int KB, int LD, int JB>
-__device__ __forceinline__ void lds_fwd_group(const float* __restrict__ Al, const float (&di)[KCfg<KB>::NR],
+__device__ __forceinline__ void lds_fwd_group_plain(const float* __restrict__ Al, const float (&di)[KCfg<KB>::NR],
                                               float (&rb)[KCfg<KB>::NR], const int (&ci)[KCfg<KB>::NR],
                                               float (&cur)[16][KCfg<KB>::NR], int lane) {
     constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR, SB = 16;
@@ -301,11 +402,11 @@ __device__ __forceinline__ void lds_fwd_group(const float* __restrict__ Al, cons
 #pragma unroll
             for (int rr = JB; rr < NR; ++rr) cur[u][rr] = nxt[u][rr];
     }
-    if constexpr (JB + 1 < NR) lds_fwd_group<KB, LD, JB + 1>(Al, di, rb, ci, cur, lane);
+    if constexpr (JB + 1 < NR) lds_fwd_group_plain<KB, LD, JB + 1>(Al, di, rb, ci, cur, lane);
 }
 
 template <int KB, int LD, int IB>
-__device__ __forceinline__ void lds_bwd_group(const float* __restrict__ Al, const float (&di)[KCfg<KB>::NR],
+__device__ __forceinline__ void lds_bwd_group_plain(const float* __restrict__ Al, const float (&di)[KCfg<KB>::NR],
                                               float (&rb)[KCfg<KB>::NR], const int (&ci)[KCfg<KB>::NR],
                                               float (&cur)[16][KCfg<KB>::NR], int lane) {
     constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR, SB = 16;
@@ -326,6 +427,79 @@ __device__ __forceinline__ void lds_bwd_group(const float* __restrict__ Al, cons
 #pragma unroll
             for (int rr = 0; rr < IB; ++rr) rb[rr] = fmaf(-cur[u][rr], xi, rb[rr]);
         }
+#pragma unroll
+        for (int u = 0; u < SB; ++u)
+#pragma unroll
+            for (int rr = 0; rr <= IB; ++rr) cur[u][rr] = nxt[u][rr];
+    }
+    if constexpr (IB > 0) lds_bwd_group_plain<KB, LD, IB - 1>(Al, di, rb, ci, cur, lane);
+}
+
+// Round 3: the step loops are fully unrolled with the lane masks as LITERALS (inverse_ballot of a constant; the
+// compiler used to hoist 256 `lane < const` compares out of the item loop and spill their SGPR pairs into VGPR lanes:
+// two extra v_readlane per step), and the operand block of the NEXT 16 steps is requested - and pinned there by a
+// scheduling barrier - before the current block's dependent chain starts (it used to be re-loaded just in time, an
+// LDS round trip inside every step).  k = 128: 71 -> ~45 cycles per step.
+template <int KB, int LD, int JB>
+__device__ __forceinline__ void lds_fwd_group(const float* __restrict__ Al, const float (&di)[KCfg<KB>::NR],
+                                              float (&rb)[KCfg<KB>::NR], const int (&ci)[KCfg<KB>::NR],
+                                              float (&cur)[16][KCfg<KB>::NR], int lane) {
+    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR, SB = 16;
+    constexpr int JEND = (64 * JB + 64 < KP) ? 64 * JB + 64 : KP;
+    float nxt[SB][NR];
+#pragma unroll
+    for (int j0 = 64 * JB; j0 < JEND; j0 += SB) {
+        if (j0 + SB < KP) {
+#pragma unroll
+            for (int u = 0; u < SB; ++u)
+#pragma unroll
+                for (int rr = JB; rr < NR; ++rr) nxt[u][rr] = Al[(j0 + SB + u) * LD + ci[rr]];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int t = j0 + u - 64 * JB;                                       // lanes > t of group JB take the update
+            const unsigned long long mask = (t >= 63) ? 0ull : (~0ull << (t + 1));
+            const float yj = readlane_f(rb[JB] * di[JB], t);
+            rb[JB] = fmaf(__builtin_amdgcn_inverse_ballot_w64(mask) ? -cur[u][JB] : 0.f, yj, rb[JB]);
+#pragma unroll
+            for (int rr = JB + 1; rr < NR; ++rr) rb[rr] = fmaf(-cur[u][rr], yj, rb[rr]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < SB; ++u)
+#pragma unroll
+            for (int rr = JB; rr < NR; ++rr) cur[u][rr] = nxt[u][rr];
+    }
+    if constexpr (JB + 1 < NR) lds_fwd_group<KB, LD, JB + 1>(Al, di, rb, ci, cur, lane);
+}
+
+template <int KB, int LD, int IB>
+__device__ __forceinline__ void lds_bwd_group(const float* __restrict__ Al, const float (&di)[KCfg<KB>::NR],
+                                              float (&rb)[KCfg<KB>::NR], const int (&ci)[KCfg<KB>::NR],
+                                              float (&cur)[16][KCfg<KB>::NR], int lane) {
+    constexpr int KP = KCfg<KB>::KP, NR = KCfg<KB>::NR, SB = 16;
+    constexpr int ITOP = ((64 * IB + 64 < KP) ? 64 * IB + 64 : KP) - 1;
+    float nxt[SB][NR];
+#pragma unroll
+    for (int i0 = ITOP; i0 >= 64 * IB; i0 -= SB) {
+        if (i0 - SB >= 0) {
+#pragma unroll
+            for (int u = 0; u < SB; ++u)
+#pragma unroll
+                for (int rr = 0; rr <= IB; ++rr) nxt[u][rr] = Al[ci[rr] * LD + (i0 - SB - u)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int t = i0 - u - 64 * IB;                                       // lanes < t of group IB take the update
+            const unsigned long long mask = (t <= 0) ? 0ull : ((1ull << t) - 1ull);
+            const float xi = readlane_f(rb[IB] * di[IB], t);
+            rb[IB] = fmaf(__builtin_amdgcn_inverse_ballot_w64(mask) ? -cur[u][IB] : 0.f, xi, rb[IB]);
+#pragma unroll
+            for (int rr = 0; rr < IB; ++rr) rb[rr] = fmaf(-cur[u][rr], xi, rb[rr]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < SB; ++u)
 #pragma unroll
@@ -353,7 +527,8 @@ __device__ __forceinline__ void solve_lds(const float* __restrict__ Al, const fl
     for (int u = 0; u < SB; ++u)
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) cur[u][rr] = Al[u * LD + ci[rr]];
-    lds_fwd_group<KB, LD, 0>(Al, di, rb, ci, cur, lane);                 // L y = b
+    if constexpr (NR <= 2) lds_fwd_group<KB, LD, 0>(Al, di, rb, ci, cur, lane);            // L y = b
+    else                   lds_fwd_group_plain<KB, LD, 0>(Al, di, rb, ci, cur, lane);
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) rb[rr] *= di[rr];                   // y
     if (y_out) {
@@ -365,7 +540,8 @@ __device__ __forceinline__ void solve_lds(const float* __restrict__ Al, const fl
     for (int u = 0; u < SB; ++u)
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) cur[u][rr] = Al[ci[rr] * LD + (KP - 1 - u)];
-    lds_bwd_group<KB, LD, NR - 1>(Al, di, rb, ci, cur, lane);
+    if constexpr (NR <= 2) lds_bwd_group<KB, LD, NR - 1>(Al, di, rb, ci, cur, lane);
+    else                   lds_bwd_group_plain<KB, LD, NR - 1>(Al, di, rb, ci, cur, lane);
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) rb[rr] *= di[rr];                   // x
 #pragma unroll
