@@ -160,11 +160,14 @@ struct KCfg {
 template <int KP>
 __device__ __forceinline__ float solve_regs(const float (&a)[KP], float di, float rb, int lane,
                                             float* y_out = nullptr) {
+    // (the lane masks are LITERALS - inverse_ballot of a constant: written as `lane > j` the 2 KP compares were hoisted
+    // out of the caller's item loop and their SGPR pairs spilled into VGPR lanes, two extra v_readlane per step)
     float rs = rb * di;
 #pragma unroll
     for (int j = 0; j < KP; ++j) {
         const float yj = readlane_f(rs, j);
-        const float cf = (lane > j) ? a[j] * di : 0.f;
+        const unsigned long long mask = (j >= 63) ? 0ull : (~0ull << (j + 1));            // lanes > j
+        const float cf = __builtin_amdgcn_inverse_ballot_w64(mask) ? a[j] * di : 0.f;
         rs = fmaf(-cf, yj, rs);
     }
     if (y_out) *y_out = rs;   // lane j holds y_j of L y = b
@@ -172,7 +175,8 @@ __device__ __forceinline__ float solve_regs(const float (&a)[KP], float di, floa
 #pragma unroll
     for (int i = KP - 1; i >= 0; --i) {
         const float xi = readlane_f(rs, i);
-        const float cf = (lane < i) ? a[i] * di : 0.f;
+        const unsigned long long mask = (i <= 0) ? 0ull : ((1ull << i) - 1ull);           // lanes < i
+        const float cf = __builtin_amdgcn_inverse_ballot_w64(mask) ? a[i] * di : 0.f;
         rs = fmaf(-cf, xi, rs);
     }
     return rs;
