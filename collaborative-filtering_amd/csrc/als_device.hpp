@@ -160,13 +160,17 @@ struct KCfg {
 template <int KP>
 __device__ __forceinline__ float solve_regs(const float (&a)[KP], float di, float rb, int lane,
                                             float* y_out = nullptr) {
-    // (the lane masks are LITERALS - inverse_ballot of a constant: written as `lane > j` the 2 KP compares were hoisted
-    // out of the caller's item loop and their SGPR pairs spilled into VGPR lanes, two extra v_readlane per step)
+    // The lane masks are made by the SCALAR unit inside the call: a shift of all-ones by (step + an opaque zero).
+    // Written as `lane > j` - or as literal masks - the 2 KP mask values are loop invariants of the caller's item loop:
+    // the compiler hoists them and, out of SGPRs, spills them into VGPR lanes - two extra v_readlane per step.
+    int zero;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+    const unsigned long long ones = ~0ull;
     float rs = rb * di;
 #pragma unroll
     for (int j = 0; j < KP; ++j) {
         const float yj = readlane_f(rs, j);
-        const unsigned long long mask = (j >= 63) ? 0ull : (~0ull << (j + 1));            // lanes > j
+        const unsigned long long mask = (j >= 63) ? 0ull : (ones << (j + 1 + zero));       // lanes > j
         const float cf = __builtin_amdgcn_inverse_ballot_w64(mask) ? a[j] * di : 0.f;
         rs = fmaf(-cf, yj, rs);
     }
@@ -175,7 +179,7 @@ __device__ __forceinline__ float solve_regs(const float (&a)[KP], float di, floa
 #pragma unroll
     for (int i = KP - 1; i >= 0; --i) {
         const float xi = readlane_f(rs, i);
-        const unsigned long long mask = (i <= 0) ? 0ull : ((1ull << i) - 1ull);           // lanes < i
+        const unsigned long long mask = (i <= 0) ? 0ull : ~(ones << (i + zero));           // lanes < i
         const float cf = __builtin_amdgcn_inverse_ballot_w64(mask) ? a[i] * di : 0.f;
         rs = fmaf(-cf, xi, rs);
     }
